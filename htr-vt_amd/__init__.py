@@ -1,0 +1,6 @@
+"""htrvt_amd -- MI355X-native (gfx950) kernels and host glue for the HTR-VT
+forward / training hot path.  The directory is named `htr-vt_amd`; import it as
+`htrvt_amd` (see /htrvt_amd.py at the repo root)."""
+from . import _lib  # noqa: F401  (raises loudly when libhtrvt_hip.so is missing)
+
+__all__ = ["_lib"]

@@ -1,0 +1,76 @@
+"""ctypes binding of libhtrvt_hip.so (the C ABI declared in include/htrvt.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is
+missing or a symbol cannot be resolved, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhtrvt_hip.so")
+
+F32, BF16 = 0, 1
+KMAJOR, MNMAJOR = 0, 1
+GATHER_NONE, GATHER_CONV_FWD, GATHER_CONV_DGRAD, GATHER_CONV_WGRAD = 0, 1, 2, 3
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("a_layout", i32), ("b_layout", i32), ("gather", i32),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("batch", i32), ("batch_inner", i32),
+        ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64),
+        ("split_k", i32),
+        ("nB", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32), ("Co", i32),
+        ("kh", i32), ("kw", i32), ("sh", i32), ("sw", i32), ("ph", i32), ("pw", i32), ("Cpad", i32),
+        ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
+        ("bias", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
+        ("A", vp), ("B", vp), ("C", vp),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol of include/htrvt.h must be listed here
+PROTOTYPES = {
+    "htrvt_version": (i32, []),
+    "htrvt_last_error": (C.c_char_p, []),
+    "htrvt_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
+    "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, vp]),
+    "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, vp]),
+    "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_pool_tokens": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "htrvt_softmax_rows": (i32, [vp, vp, i64, i32, i32, vp]),
+    "htrvt_seq_whiten_fwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
+    "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
+    "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the gfx950 kernels first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C htr-vt_amd/csrc). "
+            "There is no CPU / eager fallback for the HTR-VT hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"{what or 'htrvt'} failed ({rc}): {lib.htrvt_last_error().decode()}")

@@ -1,0 +1,93 @@
+// common.h -- shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "htrvt.h"
+
+namespace htrvt {
+
+struct bf16_t {
+  unsigned short v;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((unsigned)x.v) << 16); }
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) {
+  return x;
+}
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
+  __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  bf16_t r;
+  r.v = __builtin_bit_cast(unsigned short, b);
+  return r;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)from_f32<bf16_t>(lo).v | ((unsigned)from_f32<bf16_t>(hi).v << 16);
+}
+
+// 16-byte vector of T
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+  __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+};
+template <>
+struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    unsigned w = (&raw.x)[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    unsigned b = from_f32<bf16_t>(v).v;
+    unsigned& w = (&raw.x)[i >> 1];
+    w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 8 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace htrvt
+
+#define HTRVT_REQUIRE(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      htrvt::set_error(__VA_ARGS__);    \
+      return -1;                        \
+    }                                   \
+  } while (0)

@@ -1,0 +1,151 @@
+// ctc.hip -- fused log-softmax + CTC loss + gradient w.r.t. the logits.
+//
+// Replaces, in one launch, what model_v1/train.py:21-30 issues as
+//   preds.permute(1,0,2).log_softmax(2) ; torch.nn.CTCLoss(reduction='none',
+//   zero_infinity=True)(...).mean() ; and their autograd backward
+// (ATen's native log-alpha / log-beta / collect kernels, cuDNN disabled).
+//
+// One workgroup per sample; extended labels l' = [0,l1,0,...,0] (integer, exact)
+// sit in LDS, the S = 2L+1 states are spread over the lanes, the T time steps are
+// a serial loop with one barrier each.  alpha is spilled to a global workspace
+// (read back, L2-hot, by the beta sweep that also forms the gradient
+//   d(mean_b nll)/dlogit[b,t,c] = (softmax[b,t,c] - occupancy[b,t,c]) / B ).
+#include "common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+                                                 const int* __restrict__ tgt_len, const int* __restrict__ tgt_off,
+                                                 float* __restrict__ nll, float* __restrict__ grad,
+                                                 float* __restrict__ ws, int T, int C, int Smax, float invB) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lse = reinterpret_cast<float*>(smem_raw);  // [T]
+  int* ext = reinterpret_cast<int*>(lse + T);       // [Smax]
+  float* buf0 = reinterpret_cast<float*>(ext + Smax);
+  float* buf1 = buf0 + Smax;
+  float* occ0 = buf1 + Smax;  // [C]
+  float* occ1 = occ0 + C;
+  __shared__ float s_ll;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = tgt_len[b], S = 2 * L + 1;
+  const int* lab = targets + tgt_off[b];
+  const float* x = logits + (long long)b * T * C;
+  float* A = ws + (long long)b * T * Smax;
+
+  for (int s = tid; s < S; s += NT) ext[s] = (s & 1) ? lab[s >> 1] : 0;
+  for (int c = tid; c < 2 * C; c += NT) occ0[c] = 0.f;
+  for (int t = wave; t < T; t += NT / 64) {  // log-sum-exp of every frame, one wave per frame
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[(long long)t * C + c]);
+    m = wave_max(m);
+    float e = 0.f;
+    for (int c = lane; c < C; c += 64) e += expf(x[(long long)t * C + c] - m);
+    e = wave_sum(e);
+    if (lane == 0) lse[t] = m + logf(e);
+  }
+  __syncthreads();
+
+  // ---- alpha sweep ----
+  float* prev = buf0;
+  float* cur = buf1;
+  for (int s = tid; s < S; s += NT) {
+    float a = -INFINITY;
+    if (s < 2) a = x[ext[s]] - lse[0];
+    prev[s] = a;
+    A[s] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; ++t) {
+    const float* xt = x + (long long)t * C;
+    const float l = lse[t];
+    for (int s = tid; s < S; s += NT) {
+      const int e = ext[s];
+      const float a0 = prev[s];
+      const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+      const float a2 = (s >= 2 && e != 0 && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+      const float a = lse3(a0, a1, a2) + (xt[e] - l);
+      cur[s] = a;
+      A[(long long)t * Smax + s] = a;
+    }
+    __syncthreads();
+    float* tmp = prev;
+    prev = cur;
+    cur = tmp;
+  }
+  if (tid == 0) s_ll = lse2(prev[S - 1], S > 1 ? prev[S - 2] : -INFINITY);
+  __syncthreads();
+  const float ll = s_ll;
+  const bool feasible = ll != -INFINITY;
+  if (tid == 0) nll[b] = feasible ? -ll : 0.f;
+  if (grad == nullptr) return;
+  float* g = grad + (long long)b * T * C;
+  if (!feasible) {  // zero_infinity: zero loss and zero gradient
+    for (int i = tid; i < T * C; i += NT) g[i] = 0.f;
+    return;
+  }
+
+  // ---- beta sweep + gradient ----
+  // prev/cur are reused for beta; all reads of the alpha buffers are behind the barrier above
+  for (int t = T - 1; t >= 0; --t) {
+    const float* xt = x + (long long)t * C;
+    const float l = lse[t];
+    float* occ = (t & 1) ? occ1 : occ0;
+    for (int s = tid; s < S; s += NT) {
+      const int e = ext[s];
+      float bt;
+      if (t == T - 1) {
+        bt = (s >= S - 2) ? (xt[e] - l) : -INFINITY;
+      } else {
+        const float b0 = prev[s];
+        const float b1 = s + 1 < S ? prev[s + 1] : -INFINITY;
+        const float b2 = (s + 2 < S && ext[s + 2] != 0 && ext[s + 2] != e) ? prev[s + 2] : -INFINITY;
+        bt = lse3(b0, b1, b2) + (xt[e] - l);
+      }
+      cur[s] = bt;
+      const float ab = A[(long long)t * Smax + s] + bt;
+      if (ab != -INFINITY) atomicAdd(&occ[e], expf(ab - (xt[e] - l) - ll));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+      g[(long long)t * C + c] = (expf(xt[c] - l) - occ[c]) * invB;
+      occ[c] = 0.f;
+    }
+    float* tmp = prev;
+    prev = cur;
+    cur = tmp;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len) {
+  return (size_t)B * T * (2 * max_target_len + 1);
+}
+
+extern "C" int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
+                              float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,
+                              void* stream) {
+  HTRVT_REQUIRE(B > 0 && T > 0 && C > 0 && max_target_len >= 0, "htrvt_ctc_loss: bad shape");
+  const int Smax = 2 * max_target_len + 1;
+  const size_t smem = (size_t)(T + 3 * Smax + 2 * C) * 4;
+  HTRVT_REQUIRE(smem <= 60 * 1024, "htrvt_ctc_loss: T=%d / target length %d too large for LDS", T, max_target_len);
+  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, logits, targets, tgt_len, tgt_off, nll, grad,
+                     workspace, T, C, Smax, 1.0f / (float)B);
+  return check_launch("ctc_loss");
+}

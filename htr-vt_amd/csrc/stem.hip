@@ -1,0 +1,397 @@
+// stem.hip -- HBM-bound kernels of the CNN stem (reference resnet18.py:42-84,
+// HTR_VT.py:134-136,224-227): image whitening statistics, the Cin=1 first
+// convolution, train/eval BatchNorm coefficient kernels, BN-apply/ReLU/residual,
+// BN+ReLU+max-pool, and the final pool -> token assembly.  Activations are NHWC
+// so every kernel streams 16-byte channel vectors (coalesced, wave64).
+#include "common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ img_stats
+// one block per image; two passes (mean, then centred variance) -> {mean, rstd}
+__global__ __launch_bounds__(NT) void img_stats_kernel(const float* __restrict__ img, float* __restrict__ stats, int HW,
+                                                       float eps) {
+  __shared__ float red[8];
+  const float* x = img + (long long)blockIdx.x * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < HW; i += NT * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mean = block_sum_256(s, red) / (float)HW;
+  float q = 0.f;
+  for (int i = threadIdx.x * 4; i < HW; i += NT * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = block_sum_256(q, red) / (float)HW;
+  if (threadIdx.x == 0) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rsqrtf(var + eps);
+  }
+}
+
+// ------------------------------------------------------------------ conv1 fwd
+// one block per output row (b, ho); the 3 whitened input rows live in LDS (zero
+// halo = zero padding in whitened space); each thread owns CH consecutive output
+// channels (weights in registers) and walks the row's pixels.
+template <typename T>
+__global__ __launch_bounds__(NT) void conv1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ stats,
+                                                       const float* __restrict__ w, T* __restrict__ out,
+                                                       float* __restrict__ colstats, int H, int W, int C, int nthr) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2]
+  const int Ho = H / 2;
+  const int b = blockIdx.x / Ho, ho = blockIdx.x - b * Ho;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const int WP = W + 2;
+  for (int i = threadIdx.x; i < 3 * WP; i += NT) {
+    const int r = i / WP, c = i - r * WP;
+    const int hi = 2 * ho - 1 + r, wi = c - 1;
+    float v = 0.f;
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (img[((long long)b * H + hi) * W + wi] - mean) * rstd;
+    rows[i] = v;
+  }
+  __syncthreads();
+  const int lanes_per_pix = C / CH;
+  const int ppb = nthr / lanes_per_pix;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+  if ((int)threadIdx.x < nthr) {
+    const int cg = threadIdx.x % lanes_per_pix, p0 = threadIdx.x / lanes_per_pix;
+    float wr[CH][9];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[j][t] = w[(cg * CH + j) * 9 + t];
+    T* orow = out + ((long long)blockIdx.x * W) * C + cg * CH;
+    for (int px = p0; px < W; px += ppb) {
+      float xin[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xin[r * 3 + c] = rows[r * WP + px + c];
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a = fmaf(wr[j][t], xin[t], a);
+        s1[j] += a;
+        s2[j] += a * a;
+        o.set(j, a);
+      }
+      *reinterpret_cast<decltype(o.raw)*>(orow + (long long)px * C) = o.raw;
+    }
+  }
+  // per-channel partial sums of this row: reduce the ppb threads that share a channel group
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem_raw);  // [nthr][2*CH]
+  if ((int)threadIdx.x < nthr) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      red[threadIdx.x * 2 * CH + j] = s1[j];
+      red[threadIdx.x * 2 * CH + CH + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    const int cg = c / CH, j = c - cg * CH;
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < ppb; ++k) {
+      a += red[(k * lanes_per_pix + cg) * 2 * CH + j];
+      q += red[(k * lanes_per_pix + cg) * 2 * CH + CH + j];
+    }
+    colstats[(long long)blockIdx.x * 2 * C + c] = a;
+    colstats[(long long)blockIdx.x * 2 * C + C + c] = q;
+  }
+}
+
+// ------------------------------------------------------------------ BN coefficients
+// stage 1: rows -> S partial rows;  grid (ceil(C/64), S), block 256 = 64 channels x 4 row lanes
+__global__ __launch_bounds__(NT) void bn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows,
+                                                       int C2) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int S = gridDim.y;
+  const int per = (rows + S - 1) / S;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float a = 0.f;
+  if (c < C2)
+    for (int r = r0 + rl; r < r1; r += 4) a += partial[(long long)r * C2 + c];
+  red[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && c < C2) out[(long long)blockIdx.y * C2 + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                   float* save_mean, float* save_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += partial[(long long)r * 2 * C + c];
+    s2 += partial[(long long)r * 2 * C + C + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_rstd) save_rstd[c] = rstd;
+  if (running_mean) {
+    const double unb = count > 1.f ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ------------------------------------------------------------------ BN apply (+residual, +ReLU)
+template <typename T, int RES>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const T* __restrict__ res,
+                                                      const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                      T* __restrict__ y, long long nvec, int C, int relu) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = C / CH;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long long)gridDim.x * NT) {
+    const int c0 = (int)(i % cvec) * CH;
+    Vec16<T> v, r, o;
+    v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[i];
+    if constexpr (RES != 0) r.raw = reinterpret_cast<const decltype(r.raw)*>(res)[i];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float a = fmaf(v.get(j), scale[c0 + j], shift[c0 + j]);
+      if constexpr (RES == 1) a += r.get(j);
+      if constexpr (RES == 2) a += fmaf(r.get(j), rscale[c0 + j], rshift[c0 + j]);
+      if (relu) a = fmaxf(a, 0.f);
+      o.set(j, a);
+    }
+    reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
+  }
+}
+
+// ------------------------------------------------------------------ BN + ReLU + maxpool 3x3 s(2,1) p1
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y, int B,
+                                                             int H, int W, int C) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = C / CH, Ho = (H - 1) / 2 + 1;
+  const long long total = (long long)B * Ho * W * cvec;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int cv = (int)(i % cvec);
+    long long pix = i / cvec;
+    const int wo = (int)(pix % W);
+    pix /= W;
+    const int ho = (int)(pix % Ho), b = (int)(pix / Ho);
+    float sc[CH], sf[CH], m[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      sc[j] = scale ? scale[cv * CH + j] : 1.f;
+      sf[j] = scale ? shift[cv * CH + j] : 0.f;
+      m[j] = -INFINITY;
+    }
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int hi = 2 * ho + dy;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int wi = wo + dx;
+        if (wi < 0 || wi >= W) continue;
+        Vec16<T> v;
+        v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[(((long long)b * H + hi) * W + wi) * cvec + cv];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          float a = fmaf(v.get(j), sc[j], sf[j]);
+          if (scale) a = fmaxf(a, 0.f);
+          m[j] = fmaxf(m[j], a);
+        }
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o.set(j, m[j]);
+    reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
+  }
+}
+
+// ------------------------------------------------------------------ final maxpool + span mask + pos-embed -> tokens
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_tokens_kernel(const T* __restrict__ x, const float* __restrict__ keep,
+                                                         const float* __restrict__ mask_token,
+                                                         const float* __restrict__ pos, T* __restrict__ tok, int B, int H,
+                                                         int W, int D) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = D / CH, Ho = (H - 1) / 2 + 1, N = Ho * W;
+  const long long total = (long long)B * N * cvec;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int cv = (int)(i % cvec);
+    long long t = i / cvec;
+    const int n = (int)(t % N), b = (int)(t / N);
+    const int ho = n / W, wo = n - ho * W;
+    float m[CH];
+    const bool kept = keep == nullptr || keep[n] != 0.f;
+    if (kept) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) m[j] = -INFINITY;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int hi = 2 * ho + dy;
+        if (hi < 0 || hi >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int wi = wo + dx;
+          if (wi < 0 || wi >= W) continue;
+          Vec16<T> v;
+          v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[(((long long)b * H + hi) * W + wi) * cvec + cv];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) m[j] = fmaxf(m[j], v.get(j));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) m[j] = mask_token[cv * CH + j];
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o.set(j, m[j] + pos[(long long)n * D + cv * CH + j]);
+    reinterpret_cast<decltype(o.raw)*>(tok)[i] = o.raw;
+  }
+}
+
+inline int grid_for(long long work_items) {
+  long long g = (work_items + NT - 1) / NT;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int htrvt_img_stats(const float* img, float* stats, int B, int HW, float eps, void* stream) {
+  HTRVT_REQUIRE(HW % 4 == 0 && B > 0, "htrvt_img_stats: HW must be a multiple of 4");
+  hipLaunchKernelGGL(img_stats_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, img, stats, HW, eps);
+  return check_launch("img_stats");
+}
+
+extern "C" int htrvt_conv1_fwd(const float* img, const float* stats, const float* w, void* out, float* colstats, int B,
+                               int H, int W, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0, "htrvt_conv1_fwd: C=%d must be a multiple of %d and <= %d", C, ch,
+                NT * ch);
+  const int lanes = C / ch, nthr = (NT / lanes) * lanes;
+  size_t smem = (size_t)3 * (W + 2) * 4;
+  const size_t red = (size_t)nthr * 2 * ch * 4;
+  if (red > smem) smem = red;
+  HTRVT_REQUIRE(smem <= 64 * 1024, "htrvt_conv1_fwd: W=%d too wide for the LDS row buffer", W);
+  dim3 grid(B * (H / 2));
+  if (dtype == HTRVT_BF16)
+    hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, (bf16_t*)out,
+                       colstats, H, W, C, nthr);
+  else
+    hipLaunchKernelGGL(conv1_fwd_kernel<float>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, (float*)out,
+                       colstats, H, W, C, nthr);
+  return check_launch("conv1_fwd");
+}
+
+extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                 float* shift, float* save_mean, float* save_rstd, void* stream) {
+  // caller guarantees 64 scratch rows after `rows` rows of `partial` when rows > 256
+  const float* src = partial;
+  int r = rows;
+  if (rows > 256) {
+    float* scratch = const_cast<float*>(partial) + (long long)rows * 2 * C;
+    dim3 grid((2 * C + 63) / 64, 64);
+    hipLaunchKernelGGL(bn_reduce_kernel, grid, dim3(NT), 0, (hipStream_t)stream, partial, scratch, rows, 2 * C);
+    src = scratch;
+    r = 64;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, r, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, C);
+  return check_launch("bn_eval_coeffs");
+}
+
+extern "C" int htrvt_bn_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                              const float* rshift, void* y, int64_t npix, int C, int relu, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_apply: C=%d must be a multiple of %d", C, ch);
+  const long long nvec = npix * (C / ch);
+  const int mode = res == nullptr ? 0 : (rscale == nullptr ? 1 : 2);
+  dim3 grid(grid_for(nvec));
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BN_APPLY(T, R)                                                                                            \
+  hipLaunchKernelGGL((bn_apply_kernel<T, R>), grid, dim3(NT), 0, st, (const T*)x, scale, shift, (const T*)res, rscale, \
+                     rshift, (T*)y, nvec, C, relu)
+  if (dtype == HTRVT_BF16) {
+    if (mode == 0) LAUNCH_BN_APPLY(bf16_t, 0);
+    else if (mode == 1) LAUNCH_BN_APPLY(bf16_t, 1);
+    else LAUNCH_BN_APPLY(bf16_t, 2);
+  } else {
+    if (mode == 0) LAUNCH_BN_APPLY(float, 0);
+    else if (mode == 1) LAUNCH_BN_APPLY(float, 1);
+    else LAUNCH_BN_APPLY(float, 2);
+  }
+#undef LAUNCH_BN_APPLY
+  return check_launch("bn_apply");
+}
+
+extern "C" int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
+                                     int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_relu_maxpool: C=%d must be a multiple of %d", C, ch);
+  const long long total = (long long)B * ((H - 1) / 2 + 1) * W * (C / ch);
+  dim3 grid(grid_for(total));
+  if (dtype == HTRVT_BF16)
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, scale,
+                       shift, (bf16_t*)y, B, H, W, C);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, shift,
+                       (float*)y, B, H, W, C);
+  return check_launch("bn_relu_maxpool");
+}
+
+extern "C" int htrvt_pool_tokens(const void* x, const float* keep, const float* mask_token, const float* pos, void* tok,
+                                 int B, int H, int N, int D, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  const int Ho = (H - 1) / 2 + 1;
+  HTRVT_REQUIRE(D % ch == 0 && N % Ho == 0, "htrvt_pool_tokens: bad shape D=%d N=%d H=%d", D, N, H);
+  const int W = N / Ho;
+  const long long total = (long long)B * N * (D / ch);
+  dim3 grid(grid_for(total));
+  if (dtype == HTRVT_BF16)
+    hipLaunchKernelGGL(pool_tokens_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, keep,
+                       mask_token, pos, (bf16_t*)tok, B, H, W, D);
+  else
+    hipLaunchKernelGGL(pool_tokens_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, keep, mask_token,
+                       pos, (float*)tok, B, H, W, D);
+  return check_launch("pool_tokens");
+}

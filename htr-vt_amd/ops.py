@@ -1,0 +1,108 @@
+"""Thin tensor-level wrappers over the C ABI (include/htrvt.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every wrapper
+passes raw device pointers + sizes to libhtrvt_hip.so.  Nothing in this module
+computes with torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, GATHER_CONV_DGRAD, GATHER_CONV_FWD, GATHER_CONV_WGRAD, KMAJOR, MNMAJOR, GemmDesc, check, lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def dt(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def bk_of(dtype: torch.dtype) -> int:
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def cpad(c: int, dtype: torch.dtype) -> int:
+    b = bk_of(dtype)
+    return (c + b - 1) // b * b
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "htrvt ops need device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ConvGeom:
+    """Geometry of one NHWC convolution (resnet18.py:6-7,48,59-63)."""
+
+    def __init__(self, B, Hi, Wi, Ci, Co, k, stride, pad):
+        self.B, self.Hi, self.Wi, self.Ci, self.Co = B, Hi, Wi, Ci, Co
+        self.kh = self.kw = k
+        self.sh, self.sw = stride
+        self.ph = self.pw = pad
+        self.Ho = (Hi + 2 * pad - k) // self.sh + 1
+        self.Wo = (Wi + 2 * pad - k) // self.sw + 1
+        self.taps = k * k
+
+    def fill(self, d: GemmDesc):
+        d.nB, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = self.B, self.Hi, self.Wi, self.Ci, self.Ho, self.Wo, self.Co
+        d.kh, d.kw, d.sh, d.sw, d.ph, d.pw = self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
+
+
+def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
+         Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
+         accumulate=False, bias=None, preact=None, residual=None, colstats=None, tile=0,
+         a_off=0, b_off=0, c_off=0):
+    """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
+    is used); *_off are element offsets into them."""
+    d = GemmDesc()
+    d.dtype = dt(dtype)
+    d.a_layout, d.b_layout, d.gather = a_layout, b_layout, gather
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sA_o, d.sA_i = sA
+    d.sB_o, d.sB_i = sB
+    d.sC_o, d.sC_i = sC
+    d.split_k = split_k
+    if geom is not None:
+        geom.fill(d)
+        d.Cpad = Cpad
+    d.alpha = alpha
+    d.act = act
+    d.c_f32 = 1 if c_f32 else 0
+    d.accumulate = 1 if accumulate else 0
+    d.tile = tile
+    d.bias = ptr(bias)
+    d.preact = ptr(preact)
+    d.residual = ptr(residual)
+    d.colstats = ptr(colstats)
+    esz = A.element_size()
+    d.A = A.data_ptr() + a_off * esz
+    d.B = B.data_ptr() + b_off * B.element_size()
+    d.C = Cout.data_ptr() + c_off * Cout.element_size()
+    check(lib.htrvt_gemm(C.byref(d), stream()), "htrvt_gemm")
+    return d
+
+
+def gemm_num_mtiles(M, N, dtype, gather=0, tile=0):
+    d = GemmDesc()
+    d.dtype = dt(dtype)
+    d.M, d.N, d.K = M, N, 1
+    d.gather, d.tile = gather, tile
+    n = lib.htrvt_gemm_num_mtiles(C.byref(d))
+    if n < 0:
+        raise RuntimeError(lib.htrvt_last_error().decode())
+    return n

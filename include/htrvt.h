@@ -1,0 +1,125 @@
+/* htrvt.h -- C ABI of libhtrvt_hip.so, the MI355X (gfx950) kernels behind the
+ * HTR-VT forward / training hot path.
+ *
+ * The reference (0xk0ry/HTR-VT) has NO native layer and no FFI: every FLOP of
+ * its hot path is an ATen call issued from model_v1/model/HTR_VT.py,
+ * model_v1/model/resnet18.py and model_v1/train.py:21-30.  Each entry point
+ * below therefore cites the ATen call site(s) it replaces.  The Python drop-in
+ * boundary (create_model / forward) lives in htr-vt_amd/model/HTR_VT.py and
+ * binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by
+ *     the caller (PyTorch); the library allocates nothing and keeps no state.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it.
+ *   - return 0 on success, negative on error; htrvt_last_error() describes it.
+ *   - dtype: 0 = float32, 1 = bfloat16 (storage type of activations / packed
+ *     weights).  Statistics, biases, gains, master weights are always float32.
+ *   - activations are NHWC ([B,H,W,C]); tokens are [B,N,D] row-major.
+ */
+#ifndef HTRVT_H
+#define HTRVT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTRVT_F32 0
+#define HTRVT_BF16 1
+
+#define HTRVT_KMAJOR 0  /* element (row,k) at base + row*ld + k   */
+#define HTRVT_MNMAJOR 1 /* element (row,k) at base + k*ld + row   */
+
+#define HTRVT_GATHER_NONE 0
+#define HTRVT_GATHER_CONV_FWD 1   /* A rows = output pixels, K = taps*Cpad(Ci)  */
+#define HTRVT_GATHER_CONV_DGRAD 2 /* A rows = input pixels,  K = taps*Cpad(Co)  */
+#define HTRVT_GATHER_CONV_WGRAD 3 /* B k = output pixels, N = taps*Cpad(Ci)     */
+
+int htrvt_version(void);
+const char* htrvt_last_error(void);
+
+/* One MFMA GEMM   C[m][n] = alpha * sum_k A(m,k) * B(n,k)  (+ epilogue).
+ * Replaces: nn.Linear / torch.matmul (HTR_VT.py:22,29-37,170; timm Mlp fc1/fc2),
+ * F.conv2d 3x3 / 1x1 (resnet18.py:6-7,26-31,59-63) as implicit GEMM over NHWC,
+ * and their autograd backward (train.py:123). */
+typedef struct HtrvtGemmDesc {
+  int32_t dtype;            /* element type of A and B (and of C unless c_f32)      */
+  int32_t a_layout, b_layout;
+  int32_t gather;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc;    /* in elements                                          */
+  int32_t batch, batch_inner; /* batch index z -> (z / batch_inner, z % batch_inner) */
+  int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i; /* batch strides in elements          */
+  int32_t split_k;          /* >1: grid.z splits K, result accumulated (needs accumulate=1, c_f32=1) */
+  /* conv geometry (gather != 0) */
+  int32_t nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
+  /* epilogue */
+  float alpha;
+  int32_t act;              /* 0 none, 1 exact-erf GELU                              */
+  int32_t c_f32;            /* 1: C (and residual) are float32 regardless of dtype  */
+  int32_t accumulate;       /* 1: atomicAdd into float32 C                           */
+  int32_t tile;             /* 0 auto; else BM*1000+BN of a built instantiation     */
+  const float* bias;        /* [N] or NULL                                           */
+  void* preact;             /* same shape/type as C: value before `act`, or NULL     */
+  const void* residual;     /* same shape/type as C, added last, or NULL             */
+  float* colstats;          /* [ceil(M/BM)][2][N]: per-M-tile column sum / sum of squares of the
+                               float accumulators (before bias), or NULL           */
+  const void* A;
+  const void* B;
+  void* C;
+} HtrvtGemmDesc;
+
+int htrvt_gemm(const HtrvtGemmDesc* d, void* stream);
+/* rows of colstats (= number of M tiles) the call above will write for this desc */
+int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d);
+
+/* ---- stem helpers (resnet18.py:42-84, HTR_VT.py:134-136,224-227) ------------- */
+/* per-image mean / rstd of the raw image (param-free LayerNorm, eps 1e-5): stats[b] = {mean, rstd} */
+int htrvt_img_stats(const float* img, float* stats, int B, int HW, float eps, void* stream);
+/* conv1: whiten + 3x3 conv Cin=1 stride (2,1) pad 1 -> NHWC [B,H/2,W,C] + BN partial sums
+ * colstats[B*H/2][2][C] (one row per output image row). w: [C][9] float32. */
+int htrvt_conv1_fwd(const float* img, const float* stats, const float* w, void* out, float* colstats,
+                    int B, int H, int W, int C, int dtype, void* stream);
+/* BN statistics from partial sums: train mode.  partial [rows][2][C]; count = #elements per channel.
+ * Writes scale = gamma*rstd, shift = beta - mean*scale, saves mean/rstd, updates running stats
+ * (momentum, unbiased running_var) when running_mean != NULL. */
+int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var,
+                      float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+/* eval mode: scale/shift from running stats */
+int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, float* scale, float* shift, int C, void* stream);
+/* y = [relu]( x*scale+shift [+ (res*rscale+rshift | res)] ), NHWC, any number of pixels */
+int htrvt_bn_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                   const float* rshift, void* y, int64_t npix, int C, int relu, int dtype, void* stream);
+/* y = maxpool3x3 stride (2,1) pad 1 ( relu(x*scale+shift) ), NHWC; scale==NULL: plain maxpool of x */
+int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y,
+                          int B, int H, int W, int C, int dtype, void* stream);
+/* tokens[b][n][:] = (keep[n] ? maxpool(x)[b,0,n,:] : mask_token) + pos[n][:];  x NHWC [B,H(<=3),N,D] */
+int htrvt_pool_tokens(const void* x, const float* keep, const float* mask_token, const float* pos, void* tok,
+                      int B, int H, int N, int D, int dtype, void* stream);
+
+/* ---- encoder helpers (HTR_VT.py:27-39,68-83,169-170,236-239) ------------------ */
+int htrvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int64_t rows, int D, float eps, int dtype, void* stream);
+/* in-place row softmax of float32 scores [rows][n] -> probabilities of type dtype in `p` */
+int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, void* stream);
+/* param-free LN over all N*C logits of a sample (HTR_VT.py:136,239): in dtype -> out float32 */
+int htrvt_seq_whiten_fwd(const void* x, float* y, float* stats, int B, int NC, float eps, int dtype, void* stream);
+
+/* ---- fused log-softmax + CTC (train.py:21-30; ATen ctc_loss with cuDNN off) ---- */
+/* logits [B][T][C] float32; targets concatenated int32; tgt_len/tgt_off [B] int32.
+ * nll[b] (0 if infeasible, zero_infinity); grad[b][t][c] = d(mean_b nll)/dlogits (NULL to skip).
+ * workspace: float32, htrvt_ctc_workspace_floats(B,T,Smax) elements. */
+size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len);
+int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
+                   float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTRVT_H */

@@ -1,0 +1,156 @@
+"""GPU parity of htrvt_gemm (plain / batched / conv-gather, NT / NN / TN) against
+CPU float64 restatements of the same contraction.  Integer-valued operands make
+the bf16 and f32 MFMA paths exact, so any fragment-layout error shows as an O(1)
+difference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd import ops
+    return ops
+
+
+def _ints(shape, lo=-3, hi=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).double()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 96), (384, 192, 256), (130, 72, 40), (256, 2304, 768)])
+def test_nt_plain_exact(dtype, M, N, K):
+    ops = _ops()
+    A, B = _ints((M, K), seed=1), _ints((N, K), seed=2)
+    ref = A @ B.t()
+    a, b = A.to(dtype).cuda(), B.to(dtype).cuda()
+    c = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm(a, b, c, dtype=dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    assert torch.equal(c.double().cpu(), ref.to(dtype).double())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_nt_epilogue(dtype):
+    ops = _ops()
+    M, N, K = 192, 136, 128
+    g = torch.Generator().manual_seed(3)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a, b = A.to(dtype), B.to(dtype)
+    pre = (a.double() @ b.double().t()) * 0.5 + bias.double()
+    ref = F.gelu(pre) + res.to(dtype).double()
+    c = torch.empty(M, N, dtype=dtype, device="cuda")
+    p = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c, dtype=dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1,
+             bias=bias.cuda(), preact=p, residual=res.to(dtype).cuda())
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert (p.double().cpu() - pre).abs().max() < tol
+    assert (c.double().cpu() - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_nn_and_tn_exact(dtype):
+    ops = _ops()
+    M, N, K = 160, 96, 72
+    A, Bm = _ints((M, K), seed=4), _ints((K, N), seed=5)      # NN: B stored [K][N]
+    a, b = A.to(dtype).cuda(), Bm.to(dtype).cuda()
+    c = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm(a, b, c, dtype=dtype, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_layout=ops.MNMAJOR)
+    assert torch.equal(c.double().cpu(), (A @ Bm).to(dtype).double())
+    # TN with split-K accumulation into float32: C[M][N] = At^T Bt, At [K2][M], Bt [K2][N]
+    K2 = 1000
+    At, Bt = _ints((K2, M), -2, 3, seed=6), _ints((K2, N), -2, 3, seed=7)
+    c32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(At.to(dtype).cuda(), Bt.to(dtype).cuda(), c32, dtype=dtype, M=M, N=N, K=K2, lda=M, ldb=N, ldc=N,
+             a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, split_k=4, accumulate=True, c_f32=True)
+    assert torch.equal(c32.double().cpu(), At.t() @ Bt)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_batched_attention_strides(dtype):
+    """S = scale * Q K^T and O = P V on the [B,N,3,h,hd] qkv layout (HTR_VT.py:29-36)."""
+    ops = _ops()
+    Bn, N, h, hd = 2, 128, 3, 32
+    D = h * hd
+    qkv = _ints((Bn, N, 3, h, hd), -2, 3, seed=8)
+    q, k, v = qkv[:, :, 0].permute(0, 2, 1, 3), qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+    s_ref = q @ k.transpose(-1, -2) * 0.5
+    dq = qkv.to(dtype).cuda()
+    s = torch.empty(Bn, h, N, N, dtype=torch.float32, device="cuda")
+    ops.gemm(dq, dq, s, dtype=dtype, M=N, N=N, K=hd, lda=3 * D, ldb=3 * D, ldc=N, batch=Bn * h, batch_inner=h,
+             sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(h * N * N, N * N), b_off=D, alpha=0.5, c_f32=True)
+    assert torch.equal(s.double().cpu(), s_ref)
+    P = _ints((Bn, h, N, N), 0, 3, seed=9)
+    o_ref = (P @ v).permute(0, 2, 1, 3).reshape(Bn, N, D)
+    o = torch.empty(Bn, N, D, dtype=dtype, device="cuda")
+    ops.gemm(P.to(dtype).cuda(), dq, o, dtype=dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=D, b_layout=ops.MNMAJOR,
+             batch=Bn * h, batch_inner=h, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * D, hd), b_off=2 * D)
+    assert torch.equal(o.double().cpu(), o_ref.to(dtype).double())
+
+
+def _pack_fwd(w, cp):      # [Co,Ci,kh,kw] -> [Co][taps][Cpad]
+    Co, Ci, kh, kw = w.shape
+    out = torch.zeros(Co, kh * kw, cp, dtype=w.dtype)
+    out[:, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci)
+    return out
+
+
+def _pack_dgrad(w, cp):    # [Co,Ci,kh,kw] -> [Ci][taps][Cpad(Co)]
+    Co, Ci, kh, kw = w.shape
+    out = torch.zeros(Ci, kh * kw, cp, dtype=w.dtype)
+    out[:, :, :Co] = w.permute(1, 2, 3, 0).reshape(Ci, kh * kw, Co)
+    return out
+
+
+CONVS = [  # B, Hi, Wi, Ci, Co, k, stride, pad
+    (2, 8, 64, 16, 32, 3, (1, 1), 1),
+    (2, 16, 64, 64, 64, 3, (2, 1), 1),
+    (2, 8, 128, 64, 128, 3, (2, 2), 1),
+    (3, 4, 64, 96, 192, 1, (2, 2), 0),
+    (1, 2, 256, 192, 192, 3, (1, 1), 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_dgrad_wgrad_exact(dtype, cfg):
+    ops = _ops()
+    Bn, Hi, Wi, Ci, Co, k, stride, pad = cfg
+    x = _ints((Bn, Ci, Hi, Wi), -2, 3, seed=10).requires_grad_(True)
+    w = _ints((Co, Ci, k, k), -2, 3, seed=11).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    dy = _ints(tuple(y.shape), -2, 3, seed=12)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, k, stride, pad)
+    M = Bn * geom.Ho * geom.Wo
+    cpi, cpo = ops.cpad(Ci, dtype), ops.cpad(Co, dtype)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    wf = _pack_fwd(w.detach(), cpi).to(dtype).cuda()
+    yd = torch.empty(Bn, geom.Ho, geom.Wo, Co, dtype=dtype, device="cuda")
+    nmt = ops.gemm_num_mtiles(M, Co, dtype, gather=ops.GATHER_CONV_FWD)
+    cs = torch.zeros(nmt, 2, Co, dtype=torch.float32, device="cuda")
+    ops.gemm(xd, wf, yd, dtype=dtype, M=M, N=Co, K=geom.taps * cpi, lda=Ci, ldb=geom.taps * cpi, ldc=Co,
+             gather=ops.GATHER_CONV_FWD, geom=geom, Cpad=cpi, colstats=cs)
+    y_nhwc = y.detach().permute(0, 2, 3, 1)
+    assert torch.equal(yd.double().cpu(), y_nhwc.to(dtype).double())
+    assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(cs[:, 1].sum(0).double().cpu(), (y_nhwc.reshape(-1, Co) ** 2).sum(0), rtol=1e-6, atol=1e-3)
+    # dgrad
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    wd = _pack_dgrad(w.detach(), cpo).to(dtype).cuda()
+    dxd = torch.empty(Bn, Hi, Wi, Ci, dtype=dtype, device="cuda")
+    ops.gemm(dyd, wd, dxd, dtype=dtype, M=Bn * Hi * Wi, N=Ci, K=geom.taps * cpo, lda=Co, ldb=geom.taps * cpo, ldc=Ci,
+             gather=ops.GATHER_CONV_DGRAD, geom=geom, Cpad=cpo)
+    assert torch.equal(dxd.double().cpu(), x.grad.permute(0, 2, 3, 1).to(dtype).double())
+    # wgrad (split-K, float32 atomics)
+    dwp = torch.zeros(Co, geom.taps, cpi, dtype=torch.float32, device="cuda")
+    ops.gemm(dyd, xd, dwp, dtype=dtype, M=Co, N=geom.taps * cpi, K=M, lda=Co, ldb=Ci, ldc=geom.taps * cpi,
+             a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi,
+             split_k=3, accumulate=True, c_f32=True)
+    assert torch.equal(dwp.double().cpu(), _pack_fwd(w.grad, cpi))

@@ -2,5 +2,10 @@
 forward / training hot path.  The directory is named `htr-vt_amd`; import it as
 `htrvt_amd` (see /htrvt_amd.py at the repo root)."""
 from . import _lib  # noqa: F401  (raises loudly when libhtrvt_hip.so is missing)
+from .ctc import ctc_forward_backward, ctc_loss  # noqa: F401
+from .engine import Engine, ModelShape  # noqa: F401
 
-__all__ = ["_lib"]
+
+def create_model(nb_cls, img_size, **kwargs):
+    from .model import HTR_VT
+    return HTR_VT.create_model(nb_cls, img_size, **kwargs)

@@ -44,11 +44,29 @@ PROTOTYPES = {
     "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, vp]),
     "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
-    "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "htrvt_softmax_rows": (i32, [vp, vp, i64, i32, i32, vp]),
     "htrvt_seq_whiten_fwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
+    "htrvt_seq_whiten_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_layernorm_bwd_blocks": (i32, [i64]),
+    "htrvt_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "htrvt_softmax_bwd_rows": (i32, [vp, vp, vp, i64, i32, f32, i32, vp]),
+    "htrvt_colsum": (i32, [vp, i64, i32, i64, vp, vp, i32, i32, vp]),
+    "htrvt_rowsum_f32": (i32, [vp, i32, i32, vp, vp]),
+    "htrvt_bn_bwd_blocks": (i32, [i64]),
+    "htrvt_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "htrvt_bn_bwd_finalize": (i32, [vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "htrvt_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "htrvt_maxpool_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_pool_tokens_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_conv1_wgrad_blocks": (i32, [i32, i32]),
+    "htrvt_conv1_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
     "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
 }

@@ -1,0 +1,734 @@
+// bwd.hip -- HBM-bound backward kernels of the hot path (autograd of reference
+// HTR_VT.py:222-241 / resnet18.py:23-39,73-84, i.e. what train.py:123
+// `loss.backward()` runs in ATen): LayerNorm / softmax / sequence-whiten backward,
+// train-mode BatchNorm backward (reduce + apply, fused with the ReLU mask),
+// max-pool backward (index based), token-assembly backward, column sums for
+// bias gradients and the Cin=1 conv1 weight gradient.
+// Every parameter-gradient output is float32 and is ACCUMULATED (+=).
+#include "common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXC = 4;
+
+inline int grid_for(long long work_items, int cap = 256 * 8) {
+  long long g = (work_items + NT - 1) / NT;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ sequence whiten backward
+// y = (x-mu)*r over NC elements: dx = r*(dy - mean(dy) - y*mean(dy*y))
+template <typename T>
+__global__ __launch_bounds__(NT) void seq_whiten_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ stats, T* __restrict__ dx, int NC,
+                                                            int C, int ldo) {
+  __shared__ float red[8];
+  const float* dys = dy + (long long)blockIdx.x * NC;
+  const float* ys = y + (long long)blockIdx.x * NC;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < NC; i += NT) {
+    s1 += dys[i];
+    s2 += dys[i] * ys[i];
+  }
+  const float m1 = block_sum_256(s1, red) / (float)NC;
+  const float m2 = block_sum_256(s2, red) / (float)NC;
+  const float r = stats[2 * blockIdx.x + 1];
+  T* dxs = dx + (long long)blockIdx.x * (NC / C) * ldo;
+  for (int i = threadIdx.x; i < NC; i += NT) {
+    const int n = i / C, c = i - n * C;
+    dxs[(long long)n * ldo + c] = from_f32<T>(r * (dys[i] - m1 - ys[i] * m2));
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <typename T>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                           T* __restrict__ dx, float* __restrict__ partial, long long rows,
+                                                           int D) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);  // [4][2*D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D / CH;
+  float ag[MAXC][CH], ab[MAXC][CH];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) ag[k][j] = ab[k][j] = 0.f;
+
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], r = rstd[row];
+    Vec16<T> vx[MAXC], vd[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < nchunk) {
+        vx[k].raw = reinterpret_cast<const decltype(vx[k].raw)*>(x + row * D)[c];
+        vd[k].raw = reinterpret_cast<const decltype(vd[k].raw)*>(dy + row * D)[c];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float xh = (vx[k].get(j) - mu) * r;
+          const float d = vd[k].get(j);
+          const float g = d * gamma[c * CH + j];
+          s1 += g;
+          s2 += g * xh;
+          ag[k][j] += d * xh;
+          ab[k][j] += d;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < nchunk) {
+        Vec16<T> o, dr;
+        if (dres) dr.raw = reinterpret_cast<const decltype(dr.raw)*>(dres + row * D)[c];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float xh = (vx[k].get(j) - mu) * r;
+          float v = r * (vd[k].get(j) * gamma[c * CH + j] - m1 - xh * m2);
+          if (dres) v += dr.get(j);
+          o.set(j, v);
+        }
+        reinterpret_cast<decltype(o.raw)*>(dx + row * D)[c] = o.raw;
+      }
+    }
+  }
+  // block partial of dgamma / dbeta
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        red[wave * 2 * D + c * CH + j] = ag[k][j];
+        red[wave * 2 * D + D + c * CH + j] = ab[k][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += NT)
+    partial[(long long)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+}
+
+// ------------------------------------------------------------------ softmax backward: dS = scale * P * (dP - sum(dP*P))
+template <typename T>
+__global__ __launch_bounds__(NT) void softmax_bwd_rows_kernel(const T* __restrict__ p, const float* __restrict__ dp,
+                                                              T* __restrict__ ds, long long rows, int n, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = n / 4;
+  float4 vp[MAXC], vd[MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      if constexpr (sizeof(T) == 4) {
+        vp[k] = reinterpret_cast<const float4*>(p + row * n)[c];
+      } else {
+        const uint2 u = reinterpret_cast<const uint2*>(p + row * n)[c];
+        vp[k] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u));
+      }
+      vd[k] = reinterpret_cast<const float4*>(dp + row * n)[c];
+      s += (vp[k].x * vd[k].x + vp[k].y * vd[k].y) + (vp[k].z * vd[k].z + vp[k].w * vd[k].w);
+    }
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const float a = scale * vp[k].x * (vd[k].x - s), b = scale * vp[k].y * (vd[k].y - s);
+      const float cc = scale * vp[k].z * (vd[k].z - s), d = scale * vp[k].w * (vd[k].w - s);
+      if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<float4*>(ds + row * n)[c] = make_float4(a, b, cc, d);
+      } else {
+        uint2 o;
+        o.x = pack_bf16x2(a, b);
+        o.y = pack_bf16x2(cc, d);
+        reinterpret_cast<uint2*>(ds + row * n)[c] = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums: out[c] += sum_r x[r*ld + c]
+// optional row filter: rows whose keep[(r % keep_mod)] != 0 are skipped (masked-token gradient)
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long long rows, int cols, long long ld,
+                                                    float* __restrict__ out, const float* __restrict__ keep,
+                                                    int keep_mod) {
+  constexpr int CH = Vec16<T>::N;
+  __shared__ float red[4][64][CH];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int chunk = blockIdx.x * 64 + cl;
+  const int nchunk = cols / CH;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float a[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) a[j] = 0.f;
+  if (chunk < nchunk) {
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      if (keep != nullptr && keep[r % keep_mod] != 0.f) continue;
+      Vec16<T> v;
+      v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + r * ld + (long long)chunk * CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] += v.get(j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) red[rl][cl][j] = a[j];
+  __syncthreads();
+  if (rl == 0 && chunk < nchunk) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      atomicAdd(&out[chunk * CH + j], red[0][cl][j] + red[1][cl][j] + red[2][cl][j] + red[3][cl][j]);
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm backward (train mode)
+// pass A: partial[blk][2][C] = { sum g, sum g*xhat },  g = dy * (yact > 0 if yact)
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ yact,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ partial,
+                                                           long long npix, int C, int nthr) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);  // [nthr][2*CH]
+  const int cvec = C / CH, ppb = nthr / cvec;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+  if ((int)threadIdx.x < nthr) {
+    const int cv = threadIdx.x % cvec, pl = threadIdx.x / cvec;
+    float mu[CH], r[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      mu[j] = mean[cv * CH + j];
+      r[j] = rstd[cv * CH + j];
+    }
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+      Vec16<T> vd, vx, vy;
+      vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dy)[p * cvec + cv];
+      vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[p * cvec + cv];
+      if (yact) vy.raw = reinterpret_cast<const decltype(vy.raw)*>(yact)[p * cvec + cv];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float g = vd.get(j);
+        if (yact && !(vy.get(j) > 0.f)) g = 0.f;
+        s1[j] += g;
+        s2[j] += g * (vx.get(j) - mu[j]) * r[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      red[threadIdx.x * 2 * CH + j] = s1[j];
+      red[threadIdx.x * 2 * CH + CH + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    const int cv = c / CH, j = c - cv * CH;
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < ppb; ++k) {
+      a += red[(k * cvec + cv) * 2 * CH + j];
+      q += red[(k * cvec + cv) * 2 * CH + CH + j];
+    }
+    partial[(long long)blockIdx.x * 2 * C + c] = a;
+    partial[(long long)blockIdx.x * 2 * C + C + c] = q;
+  }
+}
+
+// finalize: dgamma += sum g*xhat ; dbeta += sum g ; coefficients of dx = cA*g + cB*x + cC
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += partial[(long long)r * 2 * C + c];
+    s2 += partial[(long long)r * 2 * C + C + c];
+  }
+  dbeta[c] += (float)s1;
+  dgamma[c] += (float)s2;
+  const double g = gamma[c], r = rstd[c], mu = mean[c];
+  coef[c] = (float)(g * r);
+  coef[C + c] = (float)(-g * r * r * s2 / count);
+  coef[2 * C + c] = (float)(-g * r * s1 / count + g * r * r * mu * s2 / count);
+}
+
+// pass B: dx = cA*g + cB*x + cC ; optionally also writes g (the ReLU-masked incoming gradient)
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ yact,
+                                                          const T* __restrict__ x, const float* __restrict__ coef,
+                                                          T* __restrict__ dx, T* __restrict__ gout, long long nvec,
+                                                          int C) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = C / CH;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long long)gridDim.x * NT) {
+    const int c0 = (int)(i % cvec) * CH;
+    Vec16<T> vd, vx, vy, o, go;
+    vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dy)[i];
+    vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
+    if (yact) vy.raw = reinterpret_cast<const decltype(vy.raw)*>(yact)[i];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float g = vd.get(j);
+      if (yact && !(vy.get(j) > 0.f)) g = 0.f;
+      go.set(j, g);
+      o.set(j, fmaf(coef[c0 + j], g, fmaf(coef[C + c0 + j], vx.get(j), coef[2 * C + c0 + j])));
+    }
+    reinterpret_cast<decltype(o.raw)*>(dx)[i] = o.raw;
+    if (gout) reinterpret_cast<decltype(go.raw)*>(gout)[i] = go.raw;
+  }
+}
+
+// ------------------------------------------------------------------ first max-pool backward (index based) + ReLU mask
+// g[b,hi,wi,c] = (x*scale+shift > 0) * sum_{windows (ho,wo) containing (hi,wi) with idx == position} dpool[b,ho,wo,c]
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ idx,
+                                                         const T* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, T* __restrict__ g, int B, int H,
+                                                         int W, int C) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = C / CH, Ho = (H - 1) / 2 + 1;
+  const long long total = (long long)B * H * W * cvec;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int cv = (int)(i % cvec);
+    long long pix = i / cvec;
+    const int wi = (int)(pix % W);
+    pix /= W;
+    const int hi = (int)(pix % H), b = (int)(pix / H);
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+    // windows: 2*ho - 1 + dy == hi, dy in 0..2
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int t = hi + 1 - dy;
+      if (t < 0 || (t & 1)) continue;
+      const int ho = t >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wo = wi + 1 - dx;
+        if (wo < 0 || wo >= W) continue;
+        const long long o = (((long long)b * Ho + ho) * W + wo) * cvec + cv;
+        Vec16<T> vd;
+        vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dpool)[o];
+        const unsigned char* ip = idx + o * CH;
+        unsigned char id[CH];
+        if constexpr (CH == 8) {
+          const uint2 u = *reinterpret_cast<const uint2*>(ip);
+          *reinterpret_cast<uint2*>(id) = u;
+        } else {
+          const unsigned u = *reinterpret_cast<const unsigned*>(ip);
+          *reinterpret_cast<unsigned*>(id) = u;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          if (id[j] == dy * 3 + dx) acc[j] += vd.get(j);
+      }
+    }
+    Vec16<T> vx, o;
+    vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float a = fmaf(vx.get(j), scale[cv * CH + j], shift[cv * CH + j]);
+      o.set(j, a > 0.f ? acc[j] : 0.f);
+    }
+    reinterpret_cast<decltype(o.raw)*>(g)[i] = o.raw;
+  }
+}
+
+// ------------------------------------------------------------------ token assembly backward (final max-pool)
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_tokens_bwd_kernel(const T* __restrict__ dtok, const T* __restrict__ x,
+                                                             const float* __restrict__ keep, T* __restrict__ dx, int B,
+                                                             int H, int W, int D) {
+  constexpr int CH = Vec16<T>::N;
+  const int cvec = D / CH, Ho = (H - 1) / 2 + 1;
+  const long long total = (long long)B * H * W * cvec;
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+    const int cv = (int)(i % cvec);
+    long long pix = i / cvec;
+    const int wi = (int)(pix % W);
+    pix /= W;
+    const int hi = (int)(pix % H), b = (int)(pix / H);
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int t = hi + 1 - dy;
+      if (t < 0 || (t & 1)) continue;
+      const int ho = t >> 1;
+      if (ho >= Ho) continue;
+      for (int dx_ = 0; dx_ < 3; ++dx_) {
+        const int wo = wi + 1 - dx_;
+        if (wo < 0 || wo >= W) continue;
+        const int n = ho * W + wo;
+        if (keep != nullptr && keep[n] == 0.f) continue;
+        // first maximum of window (ho,wo) in scan order
+        float m[CH];
+        int am[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          m[j] = -INFINITY;
+          am[j] = -1;
+        }
+        for (int r = 0; r < 3; ++r) {
+          const int h2 = 2 * ho - 1 + r;
+          if (h2 < 0 || h2 >= H) continue;
+          for (int c = 0; c < 3; ++c) {
+            const int w2 = wo - 1 + c;
+            if (w2 < 0 || w2 >= W) continue;
+            Vec16<T> v;
+            v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[(((long long)b * H + h2) * W + w2) * cvec + cv];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              const float a = v.get(j);
+              if (a > m[j]) {
+                m[j] = a;
+                am[j] = r * 3 + c;
+              }
+            }
+          }
+        }
+        Vec16<T> vd;
+        vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dtok)[((long long)b * Ho * W + n) * cvec + cv];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          if (am[j] == dy * 3 + dx_) acc[j] += vd.get(j);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o.set(j, acc[j]);
+    reinterpret_cast<decltype(o.raw)*>(dx)[i] = o.raw;
+  }
+}
+
+// ------------------------------------------------------------------ conv1 weight gradient (Cin = 1)
+// partial[blk][C*9] = sum over the block's output rows of dY[pix][c] * whitened tap
+template <typename T>
+__global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ stats,
+                                                         const T* __restrict__ dy, float* __restrict__ partial, int B,
+                                                         int H, int W, int C, int nthr) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2], later reduction scratch
+  const int Ho = H / 2, WP = W + 2;
+  const int cvec = C / CH, ppb = nthr / cvec;
+  const int cg = threadIdx.x % cvec, p0 = threadIdx.x / cvec;
+  float acc[CH][9];
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+  for (int row = blockIdx.x; row < B * Ho; row += gridDim.x) {
+    const int b = row / Ho, ho = row - b * Ho;
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * WP; i += NT) {
+      const int r = i / WP, c = i - r * WP;
+      const int hi = 2 * ho - 1 + r, wi = c - 1;
+      float v = 0.f;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (img[((long long)b * H + hi) * W + wi] - mean) * rstd;
+      rows[i] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nthr) {
+      const T* drow = dy + ((long long)row * W) * C + cg * CH;
+      for (int px = p0; px < W; px += ppb) {
+        Vec16<T> vd;
+        vd.raw = *reinterpret_cast<const decltype(vd.raw)*>(drow + (long long)px * C);
+        float xin[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xin[r * 3 + c] = rows[r * WP + px + c];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float d = vd.get(j);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[j][t] = fmaf(d, xin[t], acc[j][t]);
+        }
+      }
+    }
+  }
+  // reduce the ppb threads sharing a channel group: through global atomics on the block's partial row
+  float* prow = partial + (long long)blockIdx.x * C * 9;
+  if ((int)threadIdx.x < nthr) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(&prow[(cg * CH + j) * 9 + t], acc[j][t]);
+  }
+}
+
+// out[c] += sum_r partial[r][c]   (float32 rows)
+__global__ __launch_bounds__(NT) void rowsum_f32_kernel(const float* __restrict__ partial, int rows, int cols,
+                                                        float* __restrict__ out) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) a += partial[(long long)r * cols + c];
+  out[c] += a;
+}
+
+// ------------------------------------------------------------------ weight packing / unpacking, cast, AdamW
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgr, int Co,
+                                        int Ci, int taps, int cpi, int cpo) {
+  const long long total = (long long)Co * Ci * taps;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const long long r = i / taps;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    const T v = from_f32<T>(w[i]);
+    fwd[((long long)co * taps + t) * cpi + ci] = v;
+    if (dgr) dgr[((long long)ci * taps + t) * cpo + co] = v;
+  }
+}
+
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int Co, int Ci, int taps,
+                                         int cpi) {
+  const long long total = (long long)Co * Ci * taps;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const long long r = i / taps;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    grad[i] += packed[((long long)co * taps + t) * cpi + ci];
+  }
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+
+// decoupled weight decay Adam over one flat float32 buffer (torch.optim.AdamW semantics)
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2s) {
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float& pj = (&pp.x)[j];
+      const float gj = (&gg.x)[j];
+      float& mj = (&mm.x)[j];
+      float& vj = (&vv.x)[j];
+      pj *= (1.f - lr * wd);
+      mj = b1 * mj + (1.f - b1) * gj;
+      vj = b2 * vj + (1.f - b2) * gj * gj;
+      const float denom = sqrtf(vj) / bc2s + eps;
+      pj -= (lr / bc1) * (mj / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, ...)        \
+  do {                                        \
+    if ((dtype) == HTRVT_BF16) {              \
+      using T = bf16_t;                       \
+      KERNEL;                                 \
+    } else {                                  \
+      using T = float;                        \
+      KERNEL;                                 \
+    }                                         \
+  } while (0)
+
+extern "C" int htrvt_seq_whiten_bwd(const float* dy, const float* y, const float* stats, void* dx, int B, int N, int C,
+                                    int ldo, int dtype, void* stream) {
+  HTRVT_REQUIRE(ldo >= C, "htrvt_seq_whiten_bwd: ldo < C");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(seq_whiten_bwd_kernel<T>, dim3(B), dim3(NT), 0, (hipStream_t)stream, dy, y, stats,
+                                       (T*)dx, N * C, C, ldo));
+  return check_launch("seq_whiten_bwd");
+}
+
+extern "C" int htrvt_layernorm_bwd_blocks(int64_t rows) {
+  long long g = (rows + 3) / 4;
+  if (g > 1024) g = 1024;
+  return (int)g;
+}
+
+extern "C" int htrvt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   const void* dres, void* dx, float* partial, int64_t rows, int D, int dtype,
+                                   void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(D % ch == 0 && D / ch <= 64 * MAXC, "htrvt_layernorm_bwd: D=%d unsupported", D);
+  const size_t smem = (size_t)8 * D * 4;
+  HTRVT_REQUIRE(smem <= 64 * 1024, "htrvt_layernorm_bwd: D=%d too large", D);
+  dim3 grid(htrvt_layernorm_bwd_blocks(rows));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, grid, dim3(NT), smem, (hipStream_t)stream, (const T*)dy,
+                                       (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, partial, (long long)rows, D));
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int htrvt_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
+                                      void* stream) {
+  HTRVT_REQUIRE(n % 4 == 0 && n / 4 <= 64 * MAXC, "htrvt_softmax_bwd_rows: n=%d unsupported", n);
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)p, dp,
+                                       (T*)ds, (long long)rows, n, scale));
+  return check_launch("softmax_bwd_rows");
+}
+
+extern "C" int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, float* out, const float* keep, int keep_mod,
+                            int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(cols % ch == 0 && ld % ch == 0, "htrvt_colsum: cols/ld must be multiples of %d", ch);
+  long long splits = rows / 64;
+  if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;
+  dim3 grid((cols / ch + 63) / 64, (unsigned)splits);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)x, (long long)rows,
+                                       cols, (long long)ld, out, keep, keep_mod > 0 ? keep_mod : 1));
+  return check_launch("colsum");
+}
+
+extern "C" int htrvt_rowsum_f32(const float* partial, int rows, int cols, float* out, void* stream) {
+  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, partial, rows, cols, out);
+  return check_launch("rowsum_f32");
+}
+
+extern "C" int htrvt_bn_bwd_blocks(int64_t npix) {
+  long long g = npix / 64;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int htrvt_bn_bwd_reduce(const void* dy, const void* yact, const void* x, const float* mean, const float* rstd,
+                                   float* partial, int64_t npix, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT, "htrvt_bn_bwd_reduce: C=%d unsupported", C);
+  const int cvec = C / ch, nthr = (NT / cvec) * cvec;
+  const size_t smem = (size_t)nthr * 2 * ch * 4;
+  dim3 grid(htrvt_bn_bwd_blocks(npix));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, grid, dim3(NT), smem, (hipStream_t)stream, (const T*)dy,
+                                       (const T*)yact, (const T*)x, mean, rstd, partial, (long long)npix, C, nthr));
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int htrvt_bn_bwd_finalize(const float* partial, int rows, int C, float count, const float* gamma,
+                                     const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef,
+                                     void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, rows, C, count,
+                     gamma, mean, rstd, dgamma, dbeta, coef);
+  return check_launch("bn_bwd_finalize");
+}
+
+extern "C" int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* x, const float* coef, void* dx, void* gout,
+                                  int64_t npix, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_bwd_apply: C=%d unsupported", C);
+  const long long nvec = npix * (C / ch);
+  dim3 grid(grid_for(nvec));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
+                                       (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
+  return check_launch("bn_bwd_apply");
+}
+
+extern "C" int htrvt_maxpool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* scale,
+                                 const float* shift, void* g, int B, int H, int W, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0, "htrvt_maxpool_bwd: C=%d unsupported", C);
+  const long long total = (long long)B * H * W * (C / ch);
+  dim3 grid(grid_for(total));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dpool, idx,
+                                       (const T*)x, scale, shift, (T*)g, B, H, W, C));
+  return check_launch("maxpool_bwd");
+}
+
+extern "C" int htrvt_pool_tokens_bwd(const void* dtok, const void* x, const float* keep, void* dx, int B, int H, int N,
+                                     int D, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  const int Ho = (H - 1) / 2 + 1;
+  HTRVT_REQUIRE(D % ch == 0 && N % Ho == 0, "htrvt_pool_tokens_bwd: bad shape");
+  const int W = N / Ho;
+  const long long total = (long long)B * H * W * (D / ch);
+  dim3 grid(grid_for(total));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pool_tokens_bwd_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dtok,
+                                       (const T*)x, keep, (T*)dx, B, H, W, D));
+  return check_launch("pool_tokens_bwd");
+}
+
+extern "C" int htrvt_conv1_wgrad_blocks(int B, int H) {
+  int g = B * (H / 2);
+  return g > 512 ? 512 : g;
+}
+
+extern "C" int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, float* dw, float* partial, int B,
+                                 int H, int W, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0, "htrvt_conv1_wgrad: C=%d unsupported", C);
+  const int cvec = C / ch, nthr = (NT / cvec) * cvec;
+  const int nblk = htrvt_conv1_wgrad_blocks(B, H);
+  const size_t smem = (size_t)3 * (W + 2) * 4;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblk * C * 9 * 4, st);
+  HTRVT_REQUIRE(e == hipSuccess, "htrvt_conv1_wgrad: memset failed: %s", hipGetErrorString(e));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_wgrad_kernel<T>, dim3(nblk), dim3(NT), smem, st, img, stats, (const T*)dy,
+                                       partial, B, H, W, C, nthr));
+  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((C * 9 + NT - 1) / NT), dim3(NT), 0, st, partial, nblk, C * 9, dw);
+  return check_launch("conv1_wgrad");
+}
+
+extern "C" int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
+                                      int cpad_out, int dtype, void* stream) {
+  const long long total = (long long)Co * Ci * taps;
+  dim3 grid(grid_for(total));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
+                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out));
+  return check_launch("pack_conv_weight");
+}
+
+extern "C" int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in,
+                                       void* stream) {
+  const long long total = (long long)Co * Ci * taps;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, packed, grad, Co, Ci,
+                     taps, cpad_in);
+  return check_launch("unpack_conv_wgrad");
+}
+
+extern "C" int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+  HTRVT_REQUIRE(dtype == HTRVT_BF16, "htrvt_cast_f32: only float32 -> bfloat16");
+  hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                     (long long)n);
+  return check_launch("cast_f32");
+}
+
+extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int step, void* stream) {
+  HTRVT_REQUIRE(n % 4 == 0 && step >= 1, "htrvt_adamw: n must be a multiple of 4 and step >= 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long long)(n / 4), lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2s);
+  return check_launch("adamw");
+}

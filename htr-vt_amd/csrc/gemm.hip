@@ -236,6 +236,9 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int rb, int u, int l
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 
 // ---------------------------------------------------------------------------------------------
 // the kernel
@@ -369,7 +372,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KParams p) {
           cs2[j] += a * a;
           float v = a * p.alpha + bias;
           const long long o = coff + (long long)m * p.ldc + n;
-          if (p.preact != nullptr) {
+          if (p.act == 2) {  // backward of GELU: multiply by gelu'(saved pre-activation)
+            const float xp = p.c_f32 ? reinterpret_cast<const float*>(p.preact)[o]
+                                     : to_f32(reinterpret_cast<const T*>(p.preact)[o]);
+            v *= gelu_erf_grad(xp);
+          } else if (p.preact != nullptr) {
             if (p.c_f32)
               reinterpret_cast<float*>(p.preact)[o] = v;
             else

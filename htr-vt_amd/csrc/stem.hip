@@ -195,8 +195,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
 // ------------------------------------------------------------------ BN + ReLU + maxpool 3x3 s(2,1) p1
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, T* __restrict__ y, int B,
-                                                             int H, int W, int C) {
+                                                             const float* __restrict__ shift, T* __restrict__ y,
+                                                             unsigned char* __restrict__ idx, int B, int H, int W,
+                                                             int C) {
   constexpr int CH = Vec16<T>::N;
   const int cvec = C / CH, Ho = (H - 1) / 2 + 1;
   const long long total = (long long)B * Ho * W * cvec;
@@ -207,11 +208,13 @@ __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict
     pix /= W;
     const int ho = (int)(pix % Ho), b = (int)(pix / Ho);
     float sc[CH], sf[CH], m[CH];
+    unsigned char am[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       sc[j] = scale ? scale[cv * CH + j] : 1.f;
       sf[j] = scale ? shift[cv * CH + j] : 0.f;
       m[j] = -INFINITY;
+      am[j] = 0;
     }
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict
         for (int j = 0; j < CH; ++j) {
           float a = fmaf(v.get(j), sc[j], sf[j]);
           if (scale) a = fmaxf(a, 0.f);
-          m[j] = fmaxf(m[j], a);
+          if (a > m[j]) {  // first maximum in (row, column) scan order, as ATen's max_pool2d
+            m[j] = a;
+            am[j] = (unsigned char)((dy + 1) * 3 + (dx + 1));
+          }
         }
       }
     }
@@ -235,6 +241,12 @@ __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < CH; ++j) o.set(j, m[j]);
     reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
+    if (idx != nullptr) {
+      if constexpr (CH == 8)
+        *reinterpret_cast<uint2*>(idx + i * CH) = *reinterpret_cast<const uint2*>(am);
+      else
+        *reinterpret_cast<unsigned*>(idx + i * CH) = *reinterpret_cast<const unsigned*>(am);
+    }
   }
 }
 
@@ -364,18 +376,18 @@ extern "C" int htrvt_bn_apply(const void* x, const float* scale, const float* sh
   return check_launch("bn_apply");
 }
 
-extern "C" int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
-                                     int C, int dtype, void* stream) {
+extern "C" int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int B,
+                                     int H, int W, int C, int dtype, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_relu_maxpool: C=%d must be a multiple of %d", C, ch);
   const long long total = (long long)B * ((H - 1) / 2 + 1) * W * (C / ch);
   dim3 grid(grid_for(total));
   if (dtype == HTRVT_BF16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, scale,
-                       shift, (bf16_t*)y, B, H, W, C);
+                       shift, (bf16_t*)y, idx, B, H, W, C);
   else
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, scale, shift,
-                       (float*)y, B, H, W, C);
+                       (float*)y, idx, B, H, W, C);
   return check_launch("bn_relu_maxpool");
 }
 

@@ -1,0 +1,499 @@
+"""Host-side execution plan of the HTR-VT hot path on one MI355X.
+
+`Engine.forward` / `Engine.backward` enqueue the gfx950 kernels of
+libhtrvt_hip.so in the order of the reference forward
+(/root/reference/model_v1/model/HTR_VT.py:222-241, resnet18.py:73-84) and of its
+autograd backward (train.py:123).  All arithmetic is in the HIP kernels; torch
+only allocates buffers (`torch.empty/zeros`) and provides the stream.
+
+Activation layout: NHWC for the stem, [B,N,D] for tokens, element type
+`dtype` (float32 = parity path on f32 MFMA, bfloat16 = throughput path);
+statistics, logits, parameters and parameter gradients are float32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from ._lib import lib, check
+from .ops import KMAJOR, MNMAJOR, GATHER_CONV_DGRAD, GATHER_CONV_FWD, GATHER_CONV_WGRAD, ConvGeom, cpad, dt, gemm, ptr, stream
+
+LN_EPS = 1e-6       # HTR_VT.py:252
+WHITEN_EPS = 1e-5   # HTR_VT.py:136
+BN_EPS = 1e-5       # resnet18.py:16
+BN_MOMENTUM = 0.1
+
+
+class ModelShape:
+    """Static shape of one model (mirrors MaskedAutoencoderViT.__init__, HTR_VT.py:143-172)."""
+
+    def __init__(self, nb_cls, img_size, embed_dim, depth, num_heads, mlp_ratio=4.0, patch_size=(4, 64), ln_eps=LN_EPS):
+        self.nb_cls = int(nb_cls)
+        self.ln_eps = float(ln_eps)
+        self.H, self.W = int(img_size[0]), int(img_size[1])
+        self.D, self.depth, self.heads = int(embed_dim), int(depth), int(num_heads)
+        self.hd = self.D // self.heads
+        self.hidden = int(embed_dim * mlp_ratio)
+        self.grid = (self.H // patch_size[0], self.W // patch_size[1])
+        self.num_patches = self.grid[0] * self.grid[1]
+        assert self.D % 32 == 0 and self.D % self.heads == 0
+        assert self.H % 64 == 0 and self.W % 64 == 0, "img_size must be a multiple of 64 (HTR_VT.py:158-160)"
+
+    def stem_convs(self):
+        """(param prefix, Ci, Co, k, stride, pad) of every MFMA conv in execution order (resnet18.py:52-71)."""
+        D = self.D
+        out, inpl = [], D // 4
+        for li, (planes, stride) in enumerate(((D // 4, (2, 1)), (D // 2, (2, 2)), (D, (2, 2))), start=1):
+            p = f"patch_embed.layer{li}"
+            out.append((f"{p}.0.conv1", inpl, planes, 3, stride, 1))
+            out.append((f"{p}.0.conv2", planes, planes, 3, (1, 1), 1))
+            out.append((f"{p}.0.downsample.0", inpl, planes, 1, stride, 0))
+            out.append((f"{p}.1.conv1", planes, planes, 3, (1, 1), 1))
+            out.append((f"{p}.1.conv2", planes, planes, 3, (1, 1), 1))
+            inpl = planes
+        return out
+
+    def linears(self):
+        names = []
+        for i in range(self.depth):
+            names += [f"blocks.{i}.attn.qkv", f"blocks.{i}.attn.proj", f"blocks.{i}.mlp.fc1", f"blocks.{i}.mlp.fc2"]
+        return names + ["head"]
+
+
+class Engine:
+    def __init__(self, shape: ModelShape, dtype=torch.float32, device="cuda"):
+        self.s = shape
+        self.dtype = dtype
+        self.dev = torch.device(device)
+        self.dti = dt(dtype)
+        self._packs = {}      # name -> (version key, tensors)
+        self.saved = None
+
+    # ------------------------------------------------------------------ small helpers
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def _zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def _wkey(self, t):
+        return (t.data_ptr(), t._version)
+
+    def _lin_w(self, name, w):
+        """weight of a Linear in compute dtype ([out,in], unchanged layout)."""
+        if self.dtype == torch.float32:
+            return w
+        key = self._wkey(w)
+        ent = self._packs.get(name)
+        if ent is None or ent[0] != key:
+            buf = ent[1] if ent is not None else self._empty(*w.shape)
+            check(lib.htrvt_cast_f32(ptr(w), ptr(buf), w.numel(), self.dti, stream()), "cast_f32")
+            self._packs[name] = (key, buf)
+            return buf
+        return ent[1]
+
+    def _head_w(self, w):
+        """head weight in compute dtype, rows zero-padded to a multiple of 8 classes ([Cp][D])."""
+        C, D = w.shape
+        Cp = (C + 7) // 8 * 8
+        key = self._wkey(w)
+        ent = self._packs.get("head")
+        if ent is None or ent[0] != key:
+            buf = ent[1] if ent is not None else torch.zeros(Cp, D, dtype=self.dtype, device=self.dev)
+            if self.dtype == torch.float32:
+                buf[:C].copy_(w)          # device memcpy
+            else:
+                check(lib.htrvt_cast_f32(ptr(w), ptr(buf), w.numel(), self.dti, stream()), "cast_f32")
+            self._packs["head"] = (key, buf)
+            return buf
+        return ent[1]
+
+    def _conv_w(self, name, w):
+        """(fwd pack [Co][taps][Cpad_i], dgrad pack [Ci][taps][Cpad_o]) of a conv weight [Co,Ci,k,k]."""
+        key = self._wkey(w)
+        ent = self._packs.get(name)
+        Co, Ci, kh, kw = w.shape
+        taps = kh * kw
+        cpi, cpo = cpad(Ci, self.dtype), cpad(Co, self.dtype)
+        if ent is None or ent[0] != key:
+            if ent is None:
+                fwd = torch.zeros(Co, taps, cpi, dtype=self.dtype, device=self.dev)
+                dgr = torch.zeros(Ci, taps, cpo, dtype=self.dtype, device=self.dev)
+            else:
+                fwd, dgr = ent[1]
+            check(lib.htrvt_pack_conv_weight(ptr(w), ptr(fwd), ptr(dgr), Co, Ci, taps, cpi, cpo, self.dti, stream()),
+                  "pack_conv_weight")
+            self._packs[name] = (key, (fwd, dgr))
+            return fwd, dgr
+        return ent[1]
+
+    # ------------------------------------------------------------------ GEMM-shaped pieces
+    def linear_fwd(self, x, w, bias, out=None, act=0, preact=None, residual=None, c_f32=False):
+        M, K = x.shape
+        N = w.shape[0]
+        if out is None:
+            out = self._empty(M, N, dtype=torch.float32 if c_f32 else self.dtype)
+        gemm(x, w, out, dtype=self.dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, preact=preact,
+             residual=residual, c_f32=c_f32)
+        return out
+
+    def linear_dgrad(self, dy, w, act=0, preact=None):
+        """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(preact))."""
+        M, N = dy.shape
+        K = w.shape[1]
+        dx = self._empty(M, K)
+        gemm(dy, w, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_layout=MNMAJOR, act=act, preact=preact)
+        return dx
+
+    def _split_k(self, Mo, No, Kred):
+        tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
+        return int(max(1, min(1024 // max(tiles, 1), Kred // 512, 64)))
+
+    def linear_wgrad(self, dy, x, dw, dbias):
+        """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        gemm(dy, x, dw, dtype=self.dtype, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
+             split_k=self._split_k(N, K, M), accumulate=True, c_f32=True)
+        if dbias is not None:
+            check(lib.htrvt_colsum(ptr(dy), M, N, N, ptr(dbias), None, 1, self.dti, stream()), "colsum")
+
+    def conv_fwd(self, x, wf, g: ConvGeom, want_stats):
+        M = g.B * g.Ho * g.Wo
+        cpi = cpad(g.Ci, self.dtype)
+        y = self._empty(g.B, g.Ho, g.Wo, g.Co)
+        cs, rows = None, 0
+        if want_stats:
+            rows = ops.gemm_num_mtiles(M, g.Co, self.dtype, gather=GATHER_CONV_FWD)
+            cs = self._empty(rows + 64, 2, g.Co, dtype=torch.float32)
+        gemm(x, wf, y, dtype=self.dtype, M=M, N=g.Co, K=g.taps * cpi, lda=g.Ci, ldb=g.taps * cpi, ldc=g.Co,
+             gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs)
+        return y, cs, rows
+
+    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None):
+        cpo = cpad(g.Co, self.dtype)
+        dx = self._empty(g.B, g.Hi, g.Wi, g.Ci)
+        gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
+             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual)
+        return dx
+
+    def conv_wgrad(self, dy, x, g: ConvGeom, dw):
+        M = g.B * g.Ho * g.Wo
+        cpi = cpad(g.Ci, self.dtype)
+        packed = self._zeros(g.Co, g.taps, cpi)
+        gemm(dy, x, packed, dtype=self.dtype, M=g.Co, N=g.taps * cpi, K=M, lda=g.Co, ldb=g.Ci, ldc=g.taps * cpi,
+             a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
+             split_k=self._split_k(g.Co, g.taps * cpi, M), accumulate=True, c_f32=True)
+        check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
+
+    # ------------------------------------------------------------------ BatchNorm pieces
+    def bn_coeffs(self, P, prefix, C, train, cs=None, rows=0, count=0):
+        """returns (scale, shift, save_mean, save_rstd)"""
+        scale, shift = self._empty(C, dtype=torch.float32), self._empty(C, dtype=torch.float32)
+        if train:
+            mean, rstd = self._empty(C, dtype=torch.float32), self._empty(C, dtype=torch.float32)
+            check(lib.htrvt_bn_finalize(ptr(cs), rows, C, float(count), ptr(P[prefix + ".weight"]), ptr(P[prefix + ".bias"]),
+                                        BN_EPS, BN_MOMENTUM, ptr(P[prefix + ".running_mean"]),
+                                        ptr(P[prefix + ".running_var"]), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                                        stream()), "bn_finalize")
+            P[prefix + ".num_batches_tracked"].add_(1)
+            return scale, shift, mean, rstd
+        check(lib.htrvt_bn_eval_coeffs(ptr(P[prefix + ".weight"]), ptr(P[prefix + ".bias"]), ptr(P[prefix + ".running_mean"]),
+                                       ptr(P[prefix + ".running_var"]), BN_EPS, ptr(scale), ptr(shift), C, stream()),
+              "bn_eval_coeffs")
+        return scale, shift, None, None
+
+    def bn_apply(self, x, scale, shift, relu, res=None, rscale=None, rshift=None):
+        y = torch.empty_like(x)
+        C = x.shape[-1]
+        check(lib.htrvt_bn_apply(ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(rscale), ptr(rshift), ptr(y),
+                                 x.numel() // C, C, 1 if relu else 0, self.dti, stream()), "bn_apply")
+        return y
+
+    def bn_backward(self, dy, yact, x, prefix, P, G, mean, rstd, want_g=False):
+        """dx of train-mode BN (+ReLU mask from yact); accumulates dgamma/dbeta into G."""
+        C = x.shape[-1]
+        npix = x.numel() // C
+        nblk = lib.htrvt_bn_bwd_blocks(npix)
+        partial = self._empty(nblk, 2, C, dtype=torch.float32)
+        check(lib.htrvt_bn_bwd_reduce(ptr(dy), ptr(yact), ptr(x), ptr(mean), ptr(rstd), ptr(partial), npix, C, self.dti,
+                                      stream()), "bn_bwd_reduce")
+        coef = self._empty(3, C, dtype=torch.float32)
+        src, rows = partial, nblk
+        if nblk > 64:   # two-level reduction of the partial rows
+            red = self._zeros(2 * C)
+            check(lib.htrvt_colsum(ptr(partial), nblk, 2 * C, 2 * C, ptr(red), None, 1, 0, stream()), "colsum")
+            src, rows = red, 1
+        check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, float(npix), ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
+                                        ptr(G[prefix + ".weight"]), ptr(G[prefix + ".bias"]), ptr(coef), stream()),
+              "bn_bwd_finalize")
+        dx = torch.empty_like(x)
+        gout = torch.empty_like(x) if want_g else None
+        check(lib.htrvt_bn_bwd_apply(ptr(dy), ptr(yact), ptr(x), ptr(coef), ptr(dx), ptr(gout), npix, C, self.dti, stream()),
+              "bn_bwd_apply")
+        return dx, gout
+
+    # ------------------------------------------------------------------ LayerNorm pieces
+    def ln_fwd(self, x, gamma, beta, save):
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        mean = self._empty(rows, dtype=torch.float32) if save else None
+        rstd = self._empty(rows, dtype=torch.float32) if save else None
+        check(lib.htrvt_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, D, self.s.ln_eps, self.dti,
+                                      stream()), "layernorm_fwd")
+        return y, mean, rstd
+
+    def ln_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
+        rows, D = x.shape
+        nblk = lib.htrvt_layernorm_bwd_blocks(rows)
+        partial = self._empty(nblk, 2, D, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        check(lib.htrvt_layernorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(partial),
+                                      rows, D, self.dti, stream()), "layernorm_bwd")
+        check(lib.htrvt_colsum(ptr(partial), nblk, D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
+        check(lib.htrvt_colsum(partial.data_ptr() + 4 * D, nblk, D, 2 * D, ptr(dbeta), None, 1, 0, stream()), "colsum")
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, P, img, keep_mask=None, train=False, save=False):
+        """P: dict name -> float32 device tensor (parameters and BN buffers, reference state_dict names).
+        img: [B,1,H,W] float32.  keep_mask: None or float32 [N] (1 keep / 0 mask-token).
+        Returns float32 logits [B,N,nb_cls] (after the final param-free LayerNorm)."""
+        s = self.s
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        B, _, H, W = img.shape
+        assert (H, W) == (s.H, s.W), f"model built for {s.H}x{s.W}, got {H}x{W}"
+        st = stream()
+        sv = {} if save else None
+        C1 = s.D // 4
+
+        # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
+        stats = self._empty(B, 2, dtype=torch.float32)
+        check(lib.htrvt_img_stats(ptr(img), ptr(stats), B, H * W, WHITEN_EPS, st), "img_stats")
+        c1 = self._empty(B, H // 2, W, C1)
+        cs = self._empty(B * (H // 2) + 64, 2, C1, dtype=torch.float32) if train else self._empty(B * (H // 2), 2, C1, dtype=torch.float32)
+        w1 = P["patch_embed.conv1.weight"]
+        check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, st), "conv1_fwd")
+        sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W)
+        Hp = (H // 2 - 1) // 2 + 1
+        a = self._empty(B, Hp, W, C1)
+        idx = torch.empty(B, Hp, W, C1, dtype=torch.uint8, device=self.dev) if save else None
+        check(lib.htrvt_bn_relu_maxpool(ptr(c1), ptr(sc), ptr(sf), ptr(a), ptr(idx), B, H // 2, W, C1, self.dti, st),
+              "bn_relu_maxpool")
+        if save:
+            sv["img"], sv["stats"], sv["c1"], sv["bn1"], sv["idx"] = img, stats, c1, (sc, sf, mean, rstd), idx
+
+        # --- residual stages (resnet18.py:79-81, 23-39) ---
+        x = a
+        Hc, Wc, Cin = Hp, W, C1
+        blocks_saved = []
+        for li, (planes, stride) in enumerate(((s.D // 4, (2, 1)), (s.D // 2, (2, 2)), (s.D, (2, 2))), start=1):
+            for bi in range(2):
+                p = f"patch_embed.layer{li}.{bi}"
+                strd = stride if bi == 0 else (1, 1)
+                g1 = ConvGeom(B, Hc, Wc, Cin, planes, 3, strd, 1)
+                wf1, _ = self._conv_w(p + ".conv1", P[p + ".conv1.weight"])
+                ca, cs1, r1 = self.conv_fwd(x, wf1, g1, train)
+                bn_a = self.bn_coeffs(P, p + ".bn1", planes, train, cs1, r1, B * g1.Ho * g1.Wo)
+                a1 = self.bn_apply(ca, bn_a[0], bn_a[1], relu=True)
+                g2 = ConvGeom(B, g1.Ho, g1.Wo, planes, planes, 3, (1, 1), 1)
+                wf2, _ = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
+                cb, cs2, r2 = self.conv_fwd(a1, wf2, g2, train)
+                bn_b = self.bn_coeffs(P, p + ".bn2", planes, train, cs2, r2, B * g2.Ho * g2.Wo)
+                if bi == 0:
+                    gd = ConvGeom(B, Hc, Wc, Cin, planes, 1, strd, 0)
+                    wfd, _ = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
+                    cd, csd, rd = self.conv_fwd(x, wfd, gd, train)
+                    bn_d = self.bn_coeffs(P, p + ".downsample.1", planes, train, csd, rd, B * gd.Ho * gd.Wo)
+                    out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, res=cd, rscale=bn_d[0], rshift=bn_d[1])
+                else:
+                    gd, cd, bn_d = None, None, None
+                    out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, res=x)
+                if save:
+                    blocks_saved.append(dict(p=p, x=x, g1=g1, ca=ca, bn_a=bn_a, a1=a1, g2=g2, cb=cb, bn_b=bn_b, gd=gd, cd=cd,
+                                             bn_d=bn_d, out=out))
+                x = out
+                Hc, Wc, Cin = g1.Ho, g1.Wo, planes
+
+        # --- final maxpool + span mask + pos-embed -> tokens (resnet18.py:82, HTR_VT.py:226-231) ---
+        Ht = (Hc - 1) // 2 + 1
+        N = Ht * Wc
+        assert N == s.num_patches, f"token count {N} != num_patches {s.num_patches}"
+        D = s.D
+        tok = self._empty(B, N, D)
+        keep = None
+        if keep_mask is not None:
+            keep = keep_mask.to(device=self.dev, dtype=torch.float32).contiguous()
+        pos = P["pos_embed"].reshape(N, D)
+        check(lib.htrvt_pool_tokens(ptr(x), ptr(keep), ptr(P["mask_token"]), ptr(pos), ptr(tok), B, Hc, N, D, self.dti, st),
+              "pool_tokens")
+        if save:
+            sv["stem_blocks"], sv["l3"], sv["keep"], sv["l3_shape"] = blocks_saved, x, keep, (B, Hc, Wc)
+
+        # --- transformer blocks (HTR_VT.py:80-83, 27-39) ---
+        M = B * N
+        h, hd = s.heads, s.hd
+        scale = hd ** -0.5
+        xt = tok.view(M, D)
+        enc_saved = []
+        for i in range(s.depth):
+            p = f"blocks.{i}"
+            ln1, m1, r1 = self.ln_fwd(xt, P[p + ".norm1.weight"], P[p + ".norm1.bias"], save)
+            wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
+            qkv = self.linear_fwd(ln1, wq, P[p + ".attn.qkv.bias"])
+            S = self._empty(B * h, N, N, dtype=torch.float32)
+            gemm(qkv, qkv, S, dtype=self.dtype, M=N, N=N, K=hd, lda=3 * D, ldb=3 * D, ldc=N, batch=B * h, batch_inner=h,
+                 sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(h * N * N, N * N), b_off=D, alpha=scale, c_f32=True)
+            Pm = self._empty(B * h, N, N)
+            check(lib.htrvt_softmax_rows(ptr(S), ptr(Pm), B * h * N, N, self.dti, st), "softmax_rows")
+            del S
+            O = self._empty(M, D)
+            gemm(Pm, qkv, O, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=D, b_layout=MNMAJOR, batch=B * h,
+                 batch_inner=h, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * D, hd), b_off=2 * D)
+            wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
+            x1 = self.linear_fwd(O, wp, P[p + ".attn.proj.bias"], residual=xt)
+            ln2, m2, r2 = self.ln_fwd(x1, P[p + ".norm2.weight"], P[p + ".norm2.bias"], save)
+            w1_ = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
+            hpre = self._empty(M, s.hidden) if save else None
+            hact = self.linear_fwd(ln2, w1_, P[p + ".mlp.fc1.bias"], act=1, preact=hpre)
+            w2_ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
+            x2 = self.linear_fwd(hact, w2_, P[p + ".mlp.fc2.bias"], residual=x1)
+            if save:
+                enc_saved.append(dict(p=p, x0=xt, ln1=ln1, m1=m1, r1=r1, qkv=qkv, P=Pm, O=O, x1=x1, ln2=ln2, m2=m2, r2=r2,
+                                      hpre=hpre, h=hact))
+            xt = x2
+
+        # --- norm + head + sequence LayerNorm (HTR_VT.py:236-239) ---
+        xn, mn, rn = self.ln_fwd(xt, P["norm.weight"], P["norm.bias"], save)
+        wh = self._head_w(P["head.weight"])
+        raw = self._empty(M, s.nb_cls, dtype=torch.float32)
+        gemm(xn, wh, raw, dtype=self.dtype, M=M, N=s.nb_cls, K=D, lda=D, ldb=D, ldc=s.nb_cls, bias=P["head.bias"], c_f32=True)
+        y = self._empty(B, N, s.nb_cls, dtype=torch.float32)
+        sstats = self._empty(B, 2, dtype=torch.float32)
+        check(lib.htrvt_seq_whiten_fwd(ptr(raw), ptr(y), ptr(sstats), B, N * s.nb_cls, WHITEN_EPS, 0, st), "seq_whiten_fwd")
+        if save:
+            sv.update(enc=enc_saved, x_last=xt, xn=xn, mn=mn, rn=rn, y=y, sstats=sstats, B=B, N=N)
+            self.saved = sv
+        return y
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P, G, dy):
+        """dy: float32 [B,N,C] = dLoss/dlogits.  Accumulates dLoss/dparam into G (dict name -> float32 tensor,
+        same shapes as P; the caller zeroes it).  Uses the activations saved by forward(save=True)."""
+        sv = self.saved
+        assert sv is not None, "backward() needs forward(..., save=True)"
+        s = self.s
+        st = stream()
+        B, N, D = sv["B"], sv["N"], s.D
+        M = B * N
+        C = s.nb_cls
+        h, hd = s.heads, s.hd
+        scale = hd ** -0.5
+        dy = dy.contiguous()
+        assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
+
+        # sequence LN, head, final norm
+        Cp = (C + 7) // 8 * 8           # class dim padded so that every 16-byte chunk is aligned
+        draw = torch.zeros(M, Cp, dtype=self.dtype, device=self.dev)
+        check(lib.htrvt_seq_whiten_bwd(ptr(dy), ptr(sv["y"]), ptr(sv["sstats"]), ptr(draw), B, N, C, Cp, self.dti, st),
+              "seq_whiten_bwd")
+        wh = self._head_w(P["head.weight"])
+        dxn = self.linear_dgrad(draw, wh)
+        if Cp == C:
+            self.linear_wgrad(draw, sv["xn"], G["head.weight"], G["head.bias"])
+        else:
+            dwp, dbp = self._zeros(Cp, D), self._zeros(Cp)
+            self.linear_wgrad(draw, sv["xn"], dwp, dbp)
+            check(lib.htrvt_rowsum_f32(ptr(dwp), 1, C * D, ptr(G["head.weight"]), st), "rowsum")
+            check(lib.htrvt_rowsum_f32(ptr(dbp), 1, C, ptr(G["head.bias"]), st), "rowsum")
+        dx = self.ln_bwd(dxn, sv["x_last"], sv["mn"], sv["rn"], P["norm.weight"], None, G["norm.weight"], G["norm.bias"])
+
+        for e in reversed(sv["enc"]):
+            p = e["p"]
+            # MLP: x2 = x1 + fc2(gelu(fc1(ln2)))
+            w2_ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
+            dhpre = self.linear_dgrad(dx, w2_, act=2, preact=e["hpre"])
+            self.linear_wgrad(dx, e["h"], G[p + ".mlp.fc2.weight"], G[p + ".mlp.fc2.bias"])
+            w1_ = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
+            dln2 = self.linear_dgrad(dhpre, w1_)
+            self.linear_wgrad(dhpre, e["ln2"], G[p + ".mlp.fc1.weight"], G[p + ".mlp.fc1.bias"])
+            del dhpre
+            dx1 = self.ln_bwd(dln2, e["x1"], e["m2"], e["r2"], P[p + ".norm2.weight"], dx, G[p + ".norm2.weight"],
+                              G[p + ".norm2.bias"])
+            # attention: x1 = x0 + proj(attn(ln1))
+            wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
+            dO = self.linear_dgrad(dx1, wp)
+            self.linear_wgrad(dx1, e["O"], G[p + ".attn.proj.weight"], G[p + ".attn.proj.bias"])
+            qkv, Pm = e["qkv"], e["P"]
+            dqkv = self._empty(M, 3 * D)
+            bstr = dict(batch=B * h, batch_inner=h)
+            # dV = P^T dO
+            gemm(Pm, dO, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=D, ldc=3 * D, a_layout=MNMAJOR, b_layout=MNMAJOR,
+                 sA=(h * N * N, N * N), sB=(N * D, hd), sC=(N * 3 * D, hd), c_off=2 * D, **bstr)
+            # dP = dO V^T
+            dP = self._empty(B * h, N, N, dtype=torch.float32)
+            gemm(dO, qkv, dP, dtype=self.dtype, M=N, N=N, K=hd, lda=D, ldb=3 * D, ldc=N, sA=(N * D, hd), sB=(N * 3 * D, hd),
+                 sC=(h * N * N, N * N), b_off=2 * D, c_f32=True, **bstr)
+            dS = self._empty(B * h, N, N)
+            check(lib.htrvt_softmax_bwd_rows(ptr(Pm), ptr(dP), ptr(dS), B * h * N, N, scale, self.dti, st), "softmax_bwd_rows")
+            del dP
+            # dQ = dS K ; dK = dS^T Q
+            gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, b_layout=MNMAJOR,
+                 sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=D, c_off=0, **bstr)
+            gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, a_layout=MNMAJOR,
+                 b_layout=MNMAJOR, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=0, c_off=D, **bstr)
+            del dS
+            wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
+            dln1 = self.linear_dgrad(dqkv, wq)
+            self.linear_wgrad(dqkv, e["ln1"], G[p + ".attn.qkv.weight"], G[p + ".attn.qkv.bias"])
+            dx = self.ln_bwd(dln1, e["x0"], e["m1"], e["r1"], P[p + ".norm1.weight"], dx1, G[p + ".norm1.weight"],
+                             G[p + ".norm1.bias"])
+
+        # token assembly
+        keep = sv["keep"]
+        if keep is not None:
+            check(lib.htrvt_colsum(ptr(dx), M, D, D, ptr(G["mask_token"]), ptr(keep), N, self.dti, st), "colsum(mask_token)")
+        Bq, Hc, Wc = sv["l3_shape"]
+        dfeat = self._empty(Bq, Hc, Wc, D)
+        check(lib.htrvt_pool_tokens_bwd(ptr(dx), ptr(sv["l3"]), ptr(keep), ptr(dfeat), B, Hc, N, D, self.dti, st),
+              "pool_tokens_bwd")
+
+        # residual stages
+        dout = dfeat
+        for blk in reversed(sv["stem_blocks"]):
+            p = blk["p"]
+            # out = relu(bn2(cb) + res): g = dout * (out > 0)
+            dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3], want_g=True)
+            _, wd2 = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
+            da1 = self.conv_dgrad(dcb, wd2, blk["g2"])
+            self.conv_wgrad(dcb, blk["a1"], blk["g2"], G[p + ".conv2.weight"])
+            del dcb
+            dca, _ = self.bn_backward(da1, blk["a1"], blk["ca"], p + ".bn1", P, G, blk["bn_a"][2], blk["bn_a"][3])
+            del da1
+            _, wd1 = self._conv_w(p + ".conv1", P[p + ".conv1.weight"])
+            self.conv_wgrad(dca, blk["x"], blk["g1"], G[p + ".conv1.weight"])
+            if blk["gd"] is not None:
+                dcd, _ = self.bn_backward(gm, None, blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3])
+                _, wdd = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
+                self.conv_wgrad(dcd, blk["x"], blk["gd"], G[p + ".downsample.0.weight"])
+                dres = self.conv_dgrad(dcd, wdd, blk["gd"])
+                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=dres)
+            else:
+                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=gm)
+
+        # first maxpool + bn1 + conv1
+        img, c1 = sv["img"], sv["c1"]
+        sc, sf, mean, rstd = sv["bn1"]
+        _, Hh, W, C1 = c1.shape
+        g = torch.empty_like(c1)
+        check(lib.htrvt_maxpool_bwd(ptr(dout), ptr(sv["idx"]), ptr(c1), ptr(sc), ptr(sf), ptr(g), B, Hh, W, C1, self.dti, st),
+              "maxpool_bwd")
+        dc1, _ = self.bn_backward(g, None, c1, "patch_embed.bn1", P, G, mean, rstd)
+        del g
+        nblk = lib.htrvt_conv1_wgrad_blocks(B, 2 * Hh)
+        partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
+        check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
+                                    B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
+        self.saved = None

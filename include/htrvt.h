@@ -95,8 +95,9 @@ int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
 /* y = [relu]( x*scale+shift [+ (res*rscale+rshift | res)] ), NHWC, any number of pixels */
 int htrvt_bn_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
                    const float* rshift, void* y, int64_t npix, int C, int relu, int dtype, void* stream);
-/* y = maxpool3x3 stride (2,1) pad 1 ( relu(x*scale+shift) ), NHWC; scale==NULL: plain maxpool of x */
-int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y,
+/* y = maxpool3x3 stride (2,1) pad 1 ( relu(x*scale+shift) ), NHWC; scale==NULL: plain maxpool of x.
+ * idx (uint8 per output element, window position 0..8 of the FIRST maximum in scan order, as ATen) or NULL */
+int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
                           int B, int H, int W, int C, int dtype, void* stream);
 /* tokens[b][n][:] = (keep[n] ? maxpool(x)[b,0,n,:] : mask_token) + pos[n][:];  x NHWC [B,H(<=3),N,D] */
 int htrvt_pool_tokens(const void* x, const float* keep, const float* mask_token, const float* pos, void* tok,
@@ -118,6 +119,54 @@ size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len);
 int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
                    float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,
                    void* stream);
+
+/* ---- backward of the path (autograd of HTR_VT.py:222-241, train.py:123) -------- */
+/* Every parameter-gradient output below is float32 and is ACCUMULATED (+=). */
+/* dx = rstd*(dy - mean(dy) - y*mean(dy*y)) per sample over its N*C logits; dx has type dtype and row
+ * stride ldo >= C (pad columns are left untouched) */
+int htrvt_seq_whiten_bwd(const float* dy, const float* y, const float* stats, void* dx, int B, int N, int C, int ldo,
+                         int dtype, void* stream);
+/* LayerNorm backward: dx = LN'(dy) [+ dres]; partial[blocks][2][D] = per-block {dgamma, dbeta} */
+int htrvt_layernorm_bwd_blocks(int64_t rows);
+int htrvt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        const void* dres, void* dx, float* partial, int64_t rows, int D, int dtype, void* stream);
+/* dS = scale * P * (dP - rowsum(dP*P)) ; P, dS of type dtype, dP float32 */
+int htrvt_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
+                           void* stream);
+/* out[c] += sum_r x[r*ld + c]; rows with keep[r % keep_mod] != 0 are skipped when keep != NULL */
+int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, float* out, const float* keep, int keep_mod,
+                 int dtype, void* stream);
+int htrvt_rowsum_f32(const float* partial, int rows, int cols, float* out, void* stream);
+/* train-mode BatchNorm backward (resnet18.py:27-37 under autograd): g = dy * (yact > 0) when yact != NULL */
+int htrvt_bn_bwd_blocks(int64_t npix);
+int htrvt_bn_bwd_reduce(const void* dy, const void* yact, const void* x, const float* mean, const float* rstd,
+                        float* partial, int64_t npix, int C, int dtype, void* stream);
+int htrvt_bn_bwd_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* mean,
+                          const float* rstd, float* dgamma, float* dbeta, float* coef /* [3][C] */, void* stream);
+int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* x, const float* coef, void* dx, void* gout,
+                       int64_t npix, int C, int dtype, void* stream);
+/* backward of htrvt_bn_relu_maxpool: g = d(bn output, ReLU-masked), x = raw conv output [B,H,W,C] */
+int htrvt_maxpool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* scale, const float* shift,
+                      void* g, int B, int H, int W, int C, int dtype, void* stream);
+/* backward of htrvt_pool_tokens w.r.t. x (masked tokens pass no gradient) */
+int htrvt_pool_tokens_bwd(const void* dtok, const void* x, const float* keep, void* dx, int B, int H, int N, int D,
+                          int dtype, void* stream);
+/* dW[C][9] += sum_pix dY * whitened-input tap (autograd of htrvt_conv1_fwd); partial: [blocks][C*9] float32 scratch */
+int htrvt_conv1_wgrad_blocks(int B, int H);
+int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, float* dw, float* partial,
+                      int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---- weight layout helpers ----------------------------------------------------- */
+/* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */
+int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
+                           int cpad_out, int dtype, void* stream);
+/* grad [Co][Ci][taps] += packed [Co][taps][cpad_in] */
+int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in, void* stream);
+int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
+
+/* ---- optimizer step (train.py:94 AdamW(betas .9/.99, wd .5) as one flat launch) -- */
+int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, void* stream);
 
 #ifdef __cplusplus
 }

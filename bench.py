@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: line-images/s of one HTR-VT training step
+(forward + CTC + backward [+ RCCL gradient all-reduce] + AdamW) on synthetic
+64x1024 grey line images, batch 128 per GPU, bf16 MFMA path.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- the dominant MFMA kernel: algorithmic FLOPs / HIP-event duration, measured live
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch CPU path) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (weak scaling)")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, mask):
+    """oracle (CPU port of the reference path) on a bounded sample of the same workload"""
+    from oracle import htrvt_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))        # a 1-GPU box share is ~16 cores; more threads than cores only thrash
+    torch.set_num_threads(cores)
+    cfg = O.Config(80, (64, args.width), embed_dim=768, depth=4, num_heads=6)
+    sd = O.init_state_dict(cfg, seed=123)
+    x, tg, tl = O.synthetic_batch(args.cpu_batch, 64, args.width, 80, cfg.num_patches, seed=0)
+    times = []
+    for it in range(args.cpu_iters + 1):
+        t0 = time.perf_counter()
+        if args.forward_only:
+            with torch.no_grad():
+                y = O.forward(sd, cfg, x, train=False)
+                y.permute(1, 0, 2).log_softmax(2)
+        else:
+            O.loss_and_grads(sd, cfg, x, tg, tl, keep_mask=mask, train=True)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / len(times[1:])
+    return {"value": round(args.cpu_batch / t, 3), "unit": "line-images/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_iters} timed iterations (1 warm-up) of batch {args.cpu_batch} 64x{args.width}, "
+                      f"{'eval forward + log_softmax' if args.forward_only else 'fwd+CTC+bwd (torch autograd over the oracle)'}"
+                      f", torch CPU float32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import htrvt_amd
+    from htrvt_amd import ops
+    from htrvt_amd.ctc import ctc_forward_backward
+    from htrvt_amd.model import HTR_VT
+    from htrvt_amd.trainer import Trainer
+    from oracle import htrvt_oracle as O          # only for synthetic_batch + cpu_baseline (checker / baseline leg)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(123)                                                  # option.py default --seed 123
+    model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=dtype).to(dev)
+    N = model.num_patches
+    B = args.batch
+    x, tg, tl = O.synthetic_batch(B, 64, args.width, 80, N, seed=rank)
+    x = x.to(dev)
+    torch.manual_seed(7)
+    keep = model.generate_span_mask(N, 0.4, 8)                              # run/iam.sh: --mask-ratio 0.4 --max-span-length 8
+
+    if args.forward_only:
+        model.eval()
+        eng = model._engine(dev)
+        P = dict(model.state_dict(keep_vars=True))
+
+        def one_step():
+            y = eng.forward(P, x, train=False, save=False)
+            nll, _ = ctc_forward_backward(y, tg, tl, want_grad=False)
+            return nll
+    else:
+        model.train()
+        tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world)
+
+        def one_step():
+            return tr.step(x, tg, tl, keep_mask=keep)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- roofline leg: HIP events around every MFMA launch of two extra steps (not part of `value`) ----
+    roof = None
+    if rank == 0:
+        ops.PROFILE = {}
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        rows = []
+        for key, ent in prof.items():
+            ts = [a.elapsed_time(b) for a, b in ent["events"]]
+            rows.append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2))
+        rows.sort(reverse=True)
+        tot, key, flops, avg_ms, per_step = rows[0]
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        names = {0: "plain", 1: "conv-fwd", 2: "conv-dgrad", 3: "conv-wgrad"}
+        roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "kernel": f"gemm_kernel<{args.dtype},{names[key[3]]},a{key[1]}b{key[2]}> M={key[4]} N={key[5]} K={key[6]} batch={key[7]}",
+                "launches_per_step": per_step, "avg_ms": round(avg_ms, 4),
+                "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
+                "mfma_ms_per_step": round(sum(r[0] for r in rows) / 2, 2),
+                "all_mfma_tflops": round(sum(r[2] * len(prof[r[1]]["events"]) for r in rows) / sum(r[0] for r in rows) / 1e9, 1)}
+
+    if rank == 0:
+        out = {"metric": "line-images/sec (64x1024, B=128) fwd+bwd+CTC", "value": round(value, 1), "unit": "line-images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": ("HTR-VT base eval forward + CTC loss" if args.forward_only else
+                                        "HTR-VT base (d768/4L/6h, nb_cls 80) training step: fwd + fused CTC + bwd + AdamW"
+                                        + (" + RCCL grad all-reduce" if world > 1 else "")),
+                          "image": f"1x64x{args.width}", "batch_per_gpu": B, "global_batch": B * world,
+                          "tokens_per_image": N, "mask": "span 0.4/8 (run/iam.sh)", "parallelism": f"dp{world}",
+                          "loss": float(loss.mean().item()) if loss is not None else None},
+               "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, keep)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

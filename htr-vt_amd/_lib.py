@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: libhtrvt_hip.so must bind to the HIP runtime PyTorch-ROCm already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhtrvt_hip.so")
 
@@ -68,7 +70,7 @@ PROTOTYPES = {
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
     "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
-    "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
 }
 
 

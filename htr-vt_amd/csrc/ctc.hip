@@ -140,12 +140,12 @@ extern "C" size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len) {
 
 extern "C" int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
                               float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,
-                              void* stream) {
+                              float grad_scale, void* stream) {
   HTRVT_REQUIRE(B > 0 && T > 0 && C > 0 && max_target_len >= 0, "htrvt_ctc_loss: bad shape");
   const int Smax = 2 * max_target_len + 1;
   const size_t smem = (size_t)(T + 3 * Smax + 2 * C) * 4;
   HTRVT_REQUIRE(smem <= 60 * 1024, "htrvt_ctc_loss: T=%d / target length %d too large for LDS", T, max_target_len);
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, logits, targets, tgt_len, tgt_off, nll, grad,
-                     workspace, T, C, Smax, 1.0f / (float)B);
+                     workspace, T, C, Smax, grad_scale / (float)B);
   return check_launch("ctc_loss");
 }

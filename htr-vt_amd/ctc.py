@@ -21,7 +21,7 @@ def _prep_targets(targets, target_lengths, device):
     return tg.to(device), tl.to(device), off.to(device), maxlen
 
 
-def ctc_forward_backward(logits, targets, target_lengths, want_grad=True):
+def ctc_forward_backward(logits, targets, target_lengths, want_grad=True, grad_scale=1.0):
     """logits [B,T,C] float32 (device).  Returns (nll [B], dmean/dlogits [B,T,C] or None)."""
     assert logits.is_cuda and logits.dtype == torch.float32
     logits = logits.contiguous()
@@ -31,7 +31,7 @@ def ctc_forward_backward(logits, targets, target_lengths, want_grad=True):
     grad = torch.empty_like(logits) if want_grad else None
     ws = torch.empty(lib.htrvt_ctc_workspace_floats(B, T, maxlen), dtype=torch.float32, device=logits.device)
     check(lib.htrvt_ctc_loss(ptr(logits), ptr(tg), ptr(tl), ptr(off), ptr(nll), ptr(grad), ptr(ws), B, T, C, maxlen,
-                             stream()), "ctc_loss")
+                             float(grad_scale), stream()), "ctc_loss")
     return nll, grad
 
 

@@ -69,6 +69,7 @@ class Engine:
         self.dev = torch.device(device)
         self.dti = dt(dtype)
         self._packs = {}      # name -> (version key, tensors)
+        self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
         self.saved = None
 
     # ------------------------------------------------------------------ small helpers
@@ -79,7 +80,7 @@ class Engine:
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
 
     def _wkey(self, t):
-        return (t.data_ptr(), t._version)
+        return (t.data_ptr(), t._version, self.weights_epoch)
 
     def _lin_w(self, name, w):
         """weight of a Linear in compute dtype ([out,in], unchanged layout)."""
@@ -379,7 +380,7 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P, G, dy):
+    def backward(self, P, G, dy, after_encoder=None):
         """dy: float32 [B,N,C] = dLoss/dlogits.  Accumulates dLoss/dparam into G (dict name -> float32 tensor,
         same shapes as P; the caller zeroes it).  Uses the activations saved by forward(save=True)."""
         sv = self.saved
@@ -450,6 +451,9 @@ class Engine:
             self.linear_wgrad(dqkv, e["ln1"], G[p + ".attn.qkv.weight"], G[p + ".attn.qkv.bias"])
             dx = self.ln_bwd(dln1, e["x0"], e["m1"], e["r1"], P[p + ".norm1.weight"], dx1, G[p + ".norm1.weight"],
                              G[p + ".norm1.bias"])
+
+        if after_encoder is not None:   # every blocks.*, norm, head gradient is enqueued: DP bucket can go
+            after_encoder()
 
         # token assembly
         keep = sv["keep"]

@@ -93,8 +93,24 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.A = A.data_ptr() + a_off * esz
     d.B = B.data_ptr() + b_off * B.element_size()
     d.C = Cout.data_ptr() + c_off * Cout.element_size()
+    if PROFILE is None:
+        check(lib.htrvt_gemm(C.byref(d), stream()), "htrvt_gemm")
+        return d
+    # bench.py roofline leg: HIP events on the launch stream around this one kernel
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.htrvt_gemm(C.byref(d), stream()), "htrvt_gemm")
+    e1.record()
+    if geom is None:
+        flops = 2.0 * M * N * K * max(batch, 1)
+    else:   # algorithmic FLOPs of the convolution, whichever of fwd/dgrad/wgrad this launch is
+        flops = 2.0 * geom.B * geom.Ho * geom.Wo * geom.Co * geom.taps * geom.Ci
+    key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1))
+    PROFILE.setdefault(key, {"flops": flops, "events": []})["events"].append((e0, e1))
     return d
+
+
+PROFILE = None   # dict while bench.py measures per-kernel durations, else None
 
 
 def gemm_num_mtiles(M, N, dtype, gather=0, tile=0):

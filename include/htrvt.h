@@ -113,12 +113,13 @@ int htrvt_seq_whiten_fwd(const void* x, float* y, float* stats, int B, int NC, f
 
 /* ---- fused log-softmax + CTC (train.py:21-30; ATen ctc_loss with cuDNN off) ---- */
 /* logits [B][T][C] float32; targets concatenated int32; tgt_len/tgt_off [B] int32.
- * nll[b] (0 if infeasible, zero_infinity); grad[b][t][c] = d(mean_b nll)/dlogits (NULL to skip).
+ * nll[b] (0 if infeasible, zero_infinity); grad[b][t][c] = grad_scale * d(mean_b nll)/dlogits (NULL to skip;
+ * grad_scale = 1/world_size folds the data-parallel gradient average into the loss).
  * workspace: float32, htrvt_ctc_workspace_floats(B,T,Smax) elements. */
 size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len);
 int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
                    float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,
-                   void* stream);
+                   float grad_scale, void* stream);
 
 /* ---- backward of the path (autograd of HTR_VT.py:222-241, train.py:123) -------- */
 /* Every parameter-gradient output below is float32 and is ACCUMULATED (+=). */

@@ -382,18 +382,21 @@ def lr_cos(nb_iter, warm_up_iter, total_iter, max_lr, min_lr=1e-7):
 # ----------------------------------------------------------------------------
 # whole-step helpers used by tests / bench cpu_baseline
 # ----------------------------------------------------------------------------
-def loss_and_grads(sd, cfg: Config, x, targets, target_lengths, keep_mask=None, train=True):
+def loss_and_grads(sd, cfg: Config, x, targets, target_lengths, keep_mask=None, train=True, dtype=torch.float32):
     """fwd + CTC + bwd on CPU through torch autograd over this restatement
-    (train.py:21-30,123).  Returns (loss, logits, grads dict, bn batch stats)."""
+    (train.py:21-30,123).  dtype=torch.float64 evaluates the same graph in double
+    (the reference is float32; the float64 run is the rounding-free yardstick).
+    Returns (loss, logits, grads dict, bn batch stats)."""
     params = OrderedDict()
     for k, v in sd.items():
-        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")) and k != "pos_embed":
-            params[k] = v.detach().clone().requires_grad_(True)
-        else:
-            params[k] = v
+        if v.dtype.is_floating_point:
+            v = v.detach().to(dtype)
+            if not k.endswith(("running_mean", "running_var")) and k != "pos_embed":
+                v = v.clone().requires_grad_(True)
+        params[k] = v
     stats = {}
-    logits = forward(params, cfg, x, keep_mask=keep_mask, train=train, stats_out=stats)
-    lp = logits.float().permute(1, 0, 2).log_softmax(2)
+    logits = forward(params, cfg, x.to(dtype), keep_mask=keep_mask, train=train, stats_out=stats)
+    lp = logits.to(dtype).permute(1, 0, 2).log_softmax(2)
     T, B = lp.shape[0], lp.shape[1]
     loss = F.ctc_loss(lp, torch.as_tensor(targets, dtype=torch.int32),
                       torch.full((B,), T, dtype=torch.int32),
@@ -402,7 +405,7 @@ def loss_and_grads(sd, cfg: Config, x, targets, target_lengths, keep_mask=None, 
     loss.backward()
     grads = OrderedDict((k, v.grad.detach()) for k, v in params.items()
                         if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None)
-    return float(loss), logits.detach(), grads, stats
+    return float(loss.detach()), logits.detach(), grads, stats
 
 
 def synthetic_batch(B, H, W, nb_cls, N, seed=0):

@@ -506,6 +506,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
   }
 }
 
+// packed is the wgrad GEMM output [taps][cpi][Co]
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int Co, int Ci, int taps,
                                          int cpi) {
   const long long total = (long long)Co * Ci * taps;
@@ -513,7 +514,7 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float
     const int t = (int)(i % taps);
     const long long r = i / taps;
     const int ci = (int)(r % Ci), co = (int)(r / Ci);
-    grad[i] += packed[((long long)co * taps + t) * cpi + ci];
+    grad[i] += packed[((long long)t * cpi + ci) * Co + co];
   }
 }
 

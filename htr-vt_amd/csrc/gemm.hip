@@ -17,28 +17,13 @@
 // a 16-byte-chunk XOR swizzle (conflict-free ds_read_b128); operands whose
 // reduction index is strided in memory (dgrad / wgrad / PV) are kept in their
 // memory order and read with ds_read_b64_tr_b16 (hardware transpose).
-#include "common.h"
+#include "gemm_common.h"
 
 using namespace htrvt;
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
 constexpr int NTHREADS = 256;
-
-template <typename T>
-struct ET;
-template <>
-struct ET<float> {
-  static constexpr int CH = 4, BK = 32, SZ = 4;
-};
-template <>
-struct ET<bf16_t> {
-  static constexpr int CH = 8, BK = 64, SZ = 2;
-};
 
 template <typename T, int ROWS, int LAYOUT>
 struct TileGeom {
@@ -49,25 +34,6 @@ struct TileGeom {
   static constexpr int BYTES = STRIDE * LROWS;
   static constexpr int NLOAD = ROWS / 32;                                        // 16-B loads / thread / k-tile
   static constexpr int CPR = (LAYOUT == HTRVT_KMAJOR) ? 8 : (ROWS * SZ / 16);    // 16-B chunks per LDS row
-};
-
-struct KParams {
-  const char* A;
-  const char* B;
-  char* C;
-  int M, N, K;
-  long long lda, ldb, ldc;
-  int batch_inner;
-  long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
-  int split_k, kchunk;
-  int nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
-  float alpha;
-  int act, c_f32, accumulate;
-  const float* bias;
-  char* preact;
-  const char* residual;
-  float* colstats;
-  int tiles_m, tiles_n;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -235,11 +201,6 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int rb, int u, int l
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
-
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
@@ -275,8 +236,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KParams p) {
     coff = zo * p.sC_o + zi * p.sC_i;
   }
 
-  constexpr int ROLE_A = (GATHER == 1 || GATHER == 2) ? GATHER : 0;
-  constexpr int ROLE_B = (GATHER == 3) ? 3 : 0;
+  constexpr int ROLE_A = GATHER;  // 1/2: K-major A rows gathered; 3: MN-major A (k = output pixel) gathered
+  constexpr int ROLE_B = 0;
   Loader<T, BM, AL, ROLE_A> la;
   Loader<T, BN, BL, ROLE_B> lb;
   la.init(p, Ab, p.lda, m0, p.M);
@@ -350,76 +311,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  const int h = lane >> 5, cl = lane & 31;
-  float cs1[TN], cs2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + cl;
-      const bool nok = n < p.N;
-      const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M && nok) {
-          const float a = acc[i][j][r];
-          cs1[j] += a;
-          cs2[j] += a * a;
-          float v = a * p.alpha + bias;
-          const long long o = coff + (long long)m * p.ldc + n;
-          if (p.act == 2) {  // backward of GELU: multiply by gelu'(saved pre-activation)
-            const float xp = p.c_f32 ? reinterpret_cast<const float*>(p.preact)[o]
-                                     : to_f32(reinterpret_cast<const T*>(p.preact)[o]);
-            v *= gelu_erf_grad(xp);
-          } else if (p.preact != nullptr) {
-            if (p.c_f32)
-              reinterpret_cast<float*>(p.preact)[o] = v;
-            else
-              reinterpret_cast<T*>(p.preact)[o] = from_f32<T>(v);
-          }
-          if (p.act == 1) v = gelu_erf(v);
-          if (p.c_f32) {
-            if (p.residual != nullptr) v += reinterpret_cast<const float*>(p.residual)[o];
-            if (p.accumulate)
-              atomicAdd(reinterpret_cast<float*>(Cb) + o, v);
-            else
-              reinterpret_cast<float*>(Cb)[o] = v;
-          } else {
-            if (p.residual != nullptr) v += to_f32(reinterpret_cast<const T*>(p.residual)[o]);
-            reinterpret_cast<T*>(Cb)[o] = from_f32<T>(v);
-          }
-        }
-      }
-    }
-  }
-
-  if (p.colstats != nullptr) {  // per-M-tile column sums for train-mode BatchNorm (uniform branch)
-    float* red = reinterpret_cast<float*>(smem);  // [2 wm][BN][2]; tile buffers are dead after the last barrier
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
-      const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (h == 0) {
-        const int c = (wn * TN + j) * 32 + cl;
-        red[(wm * BN + c) * 2 + 0] = s1;
-        red[(wm * BN + c) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < BN; c += NTHREADS) {
-      const int n = n0 + c;
-      if (n < p.N) {
-        float* dst = p.colstats + (long long)tile_m * 2 * p.N;
-        dst[n] = red[c * 2] + red[(BN + c) * 2];
-        dst[p.N + n] = red[c * 2 + 1] + red[(BN + c) * 2 + 1];
-      }
-    }
-  }
+  gemm_epilogue<T, TM, TN, 2, BN, NTHREADS>(acc, p, Cb, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
 }
 
 template <typename T, int BM, int BN, int AL, int BL, int GATHER>
@@ -477,6 +369,10 @@ int pick_tile(const HtrvtGemmDesc* d, int* bm, int* bn) {
 }  // namespace
 
 extern "C" int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d) {
+  if (d->dtype == HTRVT_BF16 && d->tile == 0) {
+    const int r = gemm_dma_num_mtiles(d);
+    if (r > 0) return r;
+  }
   int bm, bn;
   if (pick_tile(d, &bm, &bn)) return -1;
   return (d->M + bm - 1) / bm;
@@ -510,7 +406,8 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
       HTRVT_REQUIRE(d->M == d->nB * d->Hi * d->Wi && d->K == taps * d->Cpad && d->N == d->Ci && d->Cpad >= d->Co,
                     "htrvt_gemm: conv dgrad extents inconsistent");
     if (d->gather == HTRVT_GATHER_CONV_WGRAD)
-      HTRVT_REQUIRE(d->K == d->nB * d->Ho * d->Wo && d->N == taps * d->Cpad && d->M == d->Co && d->Cpad >= d->Ci,
+      HTRVT_REQUIRE(d->K == d->nB * d->Ho * d->Wo && d->M == taps * d->Cpad && d->N == d->Co && d->Cpad >= d->Ci &&
+                        d->a_layout == HTRVT_MNMAJOR && d->b_layout == HTRVT_MNMAJOR,
                     "htrvt_gemm: conv wgrad extents inconsistent");
   }
   HTRVT_REQUIRE(!(d->split_k > 1) || (d->accumulate && d->c_f32 && d->batch <= 1),
@@ -541,9 +438,15 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.bias = d->bias; p.preact = (char*)d->preact; p.residual = (const char*)d->residual; p.colstats = d->colstats;
   p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
+  p.wo_shift = p.howo_shift = -1;
   const int zdim = p.split_k > 1 ? p.split_k : (d->batch > 1 ? d->batch : 1);
   HTRVT_REQUIRE((long long)p.tiles_m * p.tiles_n < (1ll << 31) && zdim < 65536, "htrvt_gemm: grid too large");
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == HTRVT_BF16 && d->tile == 0) {  // throughput path: LDS-DMA staged 256-row tiles (gemm_dma.hip)
+    KParams q = p;
+    const int r = gemm_dma_try_launch(d, q, zdim, st);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   if (d->dtype == HTRVT_BF16) {
     if (bn == 64) return dispatch_layout<bf16_t, 128, 64>(d, p, zdim, st);
     if (bn == 128) return dispatch_layout<bf16_t, 128, 128>(d, p, zdim, st);

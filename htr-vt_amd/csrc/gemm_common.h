@@ -1,0 +1,138 @@
+// gemm_common.h -- pieces shared by the two MFMA contraction kernels
+// (gemm.hip: register-staged, float32 + bfloat16, any shape;
+//  gemm_dma.hip: LDS-DMA staged bfloat16 256-row tiles, the throughput path).
+#pragma once
+#include "common.h"
+
+namespace htrvt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <typename T>
+struct ET;
+template <>
+struct ET<float> {
+  static constexpr int CH = 4, BK = 32, SZ = 4;
+};
+template <>
+struct ET<bf16_t> {
+  static constexpr int CH = 8, BK = 64, SZ = 2;
+};
+
+struct KParams {
+  const char* A;
+  const char* B;
+  char* C;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int batch_inner;
+  long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+  int split_k, kchunk;
+  int nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
+  float alpha;
+  int act, c_f32, accumulate;
+  const float* bias;
+  char* preact;
+  const char* residual;
+  float* colstats;
+  int tiles_m, tiles_n;
+  int wo_shift, howo_shift;  // log2(Wo), log2(Ho*Wo) when powers of two, else -1 (conv-wgrad pixel decode)
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// Epilogue of one wave's TM x TN block of 32x32 accumulator tiles.
+//   acc[i][j][r] is C(row = mrow0 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), col = ncol0 + 32 j + (lane&31))
+// NWM = number of waves stacked along M in the workgroup (for the BN column-sum reduction through LDS).
+template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS>
+__device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KParams& p, char* Cb, long long coff, int mrow0,
+                                              int ncol0, int wm, int n0, int tile_m, int lane, char* smem) {
+  const int h = lane >> 5, cl = lane & 31;
+  float cs1[TN], cs2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = ncol0 + j * 32 + cl;
+      const bool nok = n < p.N;
+      const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M && nok) {
+          const float a = acc[i][j][r];
+          cs1[j] += a;
+          cs2[j] += a * a;
+          float v = a * p.alpha + bias;
+          const long long o = coff + (long long)m * p.ldc + n;
+          if (p.act == 2) {  // backward of GELU: multiply by gelu'(saved pre-activation)
+            const float xp = p.c_f32 ? reinterpret_cast<const float*>(p.preact)[o]
+                                     : to_f32(reinterpret_cast<const T*>(p.preact)[o]);
+            v *= gelu_erf_grad(xp);
+          } else if (p.preact != nullptr) {
+            if (p.c_f32)
+              reinterpret_cast<float*>(p.preact)[o] = v;
+            else
+              reinterpret_cast<T*>(p.preact)[o] = from_f32<T>(v);
+          }
+          if (p.act == 1) v = gelu_erf(v);
+          if (p.c_f32) {
+            if (p.residual != nullptr) v += reinterpret_cast<const float*>(p.residual)[o];
+            if (p.accumulate)
+              atomicAdd(reinterpret_cast<float*>(Cb) + o, v);
+            else
+              reinterpret_cast<float*>(Cb)[o] = v;
+          } else {
+            if (p.residual != nullptr) v += to_f32(reinterpret_cast<const T*>(p.residual)[o]);
+            reinterpret_cast<T*>(Cb)[o] = from_f32<T>(v);
+          }
+        }
+      }
+    }
+  }
+
+  if (p.colstats != nullptr) {  // per-M-tile column sums for train-mode BatchNorm (workgroup-uniform branch)
+    float* red = reinterpret_cast<float*>(smem);  // [NWM][BN][2]; the operand tiles are dead by now
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
+      const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (h == 0) {
+        const int c = ncol0 - n0 + j * 32 + cl;
+        red[(wm * BN + c) * 2 + 0] = s1;
+        red[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN; c += NTHREADS) {
+      const int n = n0 + c;
+      if (n < p.N) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) {
+          a += red[(w * BN + c) * 2];
+          q += red[(w * BN + c) * 2 + 1];
+        }
+        float* dst = p.colstats + (long long)tile_m * 2 * p.N;
+        dst[n] = a;
+        dst[p.N + n] = q;
+      }
+    }
+  }
+}
+
+// defined in gemm_dma.hip: returns 1 if it launched, 0 if the shape is not one it serves, <0 on error
+int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st);
+int gemm_dma_num_mtiles(const HtrvtGemmDesc* d);
+
+}  // namespace htrvt

@@ -1,0 +1,381 @@
+// gemm_dma.hip -- bfloat16 throughput path of htrvt_gemm: 256 x BN x 64 tiles,
+// 512 threads = 8 waves (4 along M x 2 along N, each 64 x BN/2), operand tiles
+// moved global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging,
+// no ds_write), double buffered: the DMA of k-tile t+1 is in flight while k-tile t
+// is multiplied (v_mfma_f32_32x32x16_bf16), one barrier per k-tile.
+//
+// Why buffer loads: an out-of-range byte offset makes the hardware deliver zeros,
+// so image-border taps of the implicit-GEMM convolutions (zero padding), M/N/K
+// tails and strided-dgrad "holes" cost no branch -- an invalid 16-byte chunk simply
+// gets the offset 0x80000000 (every operand is < 2 GiB).
+//
+// LDS images (DMA writes lane-linear: base + 16*lane, so any swizzle is applied to
+// the per-lane SOURCE chunk and again on the read):
+//   K-major operand  : [rows][128 B], 16-byte chunk c stored at c ^ (row & 7)     -> ds_read_b128, conflict-free
+//   MN-major operand : [64 k][rows*2 B], chunk c stored at (c + 4*(k&3)) mod CPR  -> ds_read_b64_tr_b16 (transpose)
+#include "gemm_common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int NTH = 512;
+constexpr int BM = 256;
+constexpr int BK = 64;
+constexpr unsigned OOB = 0x80000000u;
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA piece: 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB).  Inline asm on purpose: hipcc would
+// otherwise order every later ds_read behind the DMA with s_waitcnt vmcnt(0) (it cannot prove the two LDS stages
+// disjoint), which serialises load and MFMA.  The kernel counts these loads itself (vmcnt before the barrier).
+__device__ __forceinline__ void dma16(const i32x4_t& rsrc, unsigned lds_addr, unsigned voff) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(rsrc)
+      : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <int ROWS>
+struct Geo {
+  static constexpr int BYTES = ROWS * 128;      // both layouts: ROWS * 64 k * 2 B
+  static constexpr int NP = ROWS / 64;          // 1-KiB DMA pieces per wave per k-tile
+  static constexpr int CPR_MN = ROWS / 8;       // 16-byte chunks per k-row of an MN-major tile
+  static constexpr int ROT = (ROWS >= 128) ? 4 : 0;
+};
+
+__device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int& ho, int& wo) {
+  if (p.howo_shift >= 0) {
+    b = m >> p.howo_shift;
+    const int r = m & ((1 << p.howo_shift) - 1);
+    ho = r >> p.wo_shift;
+    wo = r & ((1 << p.wo_shift) - 1);
+  } else {
+    const int hw = p.Ho * p.Wo;
+    b = m / hw;
+    const int r = m - b * hw;
+    ho = r / p.Wo;
+    wo = r - ho * p.Wo;
+  }
+}
+
+// ROLE: 0 plain, 1 conv-fwd rows, 2 conv-dgrad rows (K-major), 3 conv-wgrad (MN-major, k = output pixel)
+template <int ROWS, int LAYOUT, int ROLE>
+struct DmaLoader {
+  using G = Geo<ROWS>;
+  static constexpr int NP = G::NP;
+  unsigned off0[NP];
+  int c0[NP], c1[NP], c2[NP];
+  bool ok[NP];
+  i32x4_t rsrc;
+  unsigned ld2;  // leading dimension in bytes
+
+  __device__ __forceinline__ void init(const KParams& p, const char* base, long long ld, int row0, int rows_total, int wave,
+                                       int lane) {
+    const unsigned long long ba = (unsigned long long)base;  // raw buffer, stride 0, 2 GiB of records
+    rsrc = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
+    ld2 = (unsigned)(ld * 2);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int pi = wave + 8 * i;
+      if constexpr (LAYOUT == HTRVT_KMAJOR) {
+        const int rl = pi * 8 + (lane >> 3);
+        const int cg = (lane & 7) ^ (rl & 7);
+        const int row = row0 + rl;
+        ok[i] = row < rows_total;
+        c2[i] = cg * 8;
+        if constexpr (ROLE == 0) {
+          off0[i] = (unsigned)row * ld2 + cg * 16;
+          c0[i] = c1[i] = 0;
+        } else if constexpr (ROLE == 1) {
+          int b, ho, wo;
+          const int hw = p.Ho * p.Wo;
+          b = row / hw;
+          const int r = row - b * hw;
+          ho = r / p.Wo;
+          wo = r - ho * p.Wo;
+          off0[i] = (unsigned)b * p.Hi * p.Wi * p.Ci * 2;
+          c0[i] = ho * p.sh - p.ph;
+          c1[i] = wo * p.sw - p.pw;
+        } else {
+          const int hw = p.Hi * p.Wi;
+          const int b = row / hw, r = row - b * hw;
+          const int hi = r / p.Wi, wi = r - hi * p.Wi;
+          off0[i] = (unsigned)b * p.Ho * p.Wo * p.Co * 2;
+          c0[i] = hi + p.ph;
+          c1[i] = wi + p.pw;
+        }
+      } else {
+        const int s = pi * 64 + lane;
+        const int krow = s / G::CPR_MN, cl = s - krow * G::CPR_MN;
+        int cg = cl - G::ROT * (krow & 3);
+        if (cg < 0) cg += G::CPR_MN;
+        const int col = row0 + cg * 8;
+        c2[i] = krow;
+        if constexpr (ROLE == 0) {
+          ok[i] = col < rows_total;
+          off0[i] = (unsigned)col * 2;
+          c0[i] = c1[i] = 0;
+        } else {  // ROLE 3: col = tap*Cpad + ci
+          const int tap = col / p.Cpad, ci = col - tap * p.Cpad;
+          const int dy = tap / p.kw, dx = tap - dy * p.kw;
+          ok[i] = (col < rows_total) && (ci < p.Ci);
+          off0[i] = (unsigned)ci * 2;
+          c0[i] = dy - p.ph;
+          c1[i] = dx - p.pw;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void issue(const KParams& p, unsigned lds_tile, int k0, int kend, int wave) {
+    int tap_dy = 0, tap_dx = 0, cbase = k0;
+    if constexpr (ROLE == 1 || ROLE == 2) {
+      const int tap = k0 / p.Cpad;
+      cbase = k0 - tap * p.Cpad;
+      tap_dy = tap / p.kw;
+      tap_dx = tap - tap_dy * p.kw;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      bool v = ok[i];
+      unsigned off = off0[i];
+      if constexpr (LAYOUT == HTRVT_KMAJOR) {
+        if constexpr (ROLE == 0) {
+          v = v && (k0 + c2[i] < kend);
+          off += (unsigned)k0 * 2;
+        } else if constexpr (ROLE == 1) {
+          const int hi = c0[i] + tap_dy, wi = c1[i] + tap_dx, c = cbase + c2[i];
+          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi) && (c < p.Ci);
+          off += (unsigned)((hi * p.Wi + wi) * p.Ci + c) * 2;
+        } else {
+          const int th = c0[i] - tap_dy, tw = c1[i] - tap_dx, c = cbase + c2[i];
+          const int ho = th >> (p.sh - 1), wo = tw >> (p.sw - 1);
+          v = v && (th >= 0) && (tw >= 0) && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0) && (ho < p.Ho) &&
+              (wo < p.Wo) && (c < p.Co);
+          off += (unsigned)((ho * p.Wo + wo) * p.Co + c) * 2;
+        }
+      } else {
+        const int k = k0 + c2[i];
+        v = v && (k < kend);
+        if constexpr (ROLE == 0) {
+          off += (unsigned)k * ld2;
+        } else {
+          int b, ho, wo;
+          pix_decode(p, k, b, ho, wo);
+          const int hi = ho * p.sh + c0[i], wi = wo * p.sw + c1[i];
+          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+          off += (unsigned)(((b * p.Hi + hi) * p.Wi + wi) * p.Ci) * 2;
+        }
+      }
+      const unsigned voff = v ? off : OOB;
+      dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_tile + (wave + 8 * i) * 1024), voff);
+    }
+  }
+};
+
+template <int ROWS, int LAYOUT>
+__device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, int lane) {
+  using G = Geo<ROWS>;
+  if constexpr (LAYOUT == HTRVT_KMAJOR) {
+    const int row = rb * 32 + (lane & 31);
+    const int chunk = 2 * s + (lane >> 5);
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
+    int chunk = rb * 4 + 2 * (g & 1) + (pp >> 1) + G::ROT * q;
+    if (chunk >= G::CPR_MN) chunk -= G::CPR_MN;
+    const int krow = 16 * s + 8 * h + q;
+    const char* a0 = lds + krow * (ROWS * 2) + chunk * 16 + (pp & 1) * 8;
+    typedef __attribute__((address_space(3))) s16x4_t* lptr;
+    const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+    const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * (ROWS * 2)));
+    const s16x8_t r = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+template <int BN, int AL, int BL, int GATHER>
+__global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
+  using T = bf16_t;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int A_BYTES = Geo<BM>::BYTES, B_BYTES = Geo<BN>::BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = blockIdx.x;
+  if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const char* Ab = p.A;
+  const char* Bb = p.B;
+  int kbeg = 0, kend = p.K;
+  long long coff = 0;
+  if (p.split_k > 1) {
+    kbeg = z * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+  } else {
+    const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+    Ab += (zo * p.sA_o + zi * p.sA_i) * 2;
+    Bb += (zo * p.sB_o + zi * p.sB_i) * 2;
+    coff = zo * p.sC_o + zi * p.sC_i;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  DmaLoader<BM, AL, GATHER> la;
+  DmaLoader<BN, BL, 0> lb;
+  la.init(p, Ab, p.lda, m0, p.M, wave, lane);
+  lb.init(p, Bb, p.ldb, n0, p.N, wave, lane);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const unsigned lds0 = lds_addr_of(smem);
+  if (nkt > 0) {
+    la.issue(p, lds0, kbeg, kend, wave);
+    lb.issue(p, lds0 + A_BYTES, kbeg, kend, wave);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    const unsigned nxt = lds0 + ((kt + 1) & 1) * STAGE;
+    if (kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
+      la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, wave);
+      lb.issue(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, wave);
+    }
+    const char* sa = cur;
+    const char* sb = cur + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  gemm_epilogue<T, TM, TN, 4, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
+}
+
+template <int BN, int AL, int BL, int GATHER>
+int launch(const KParams& p, int zdim, hipStream_t st) {
+  constexpr int smem = 2 * (Geo<BM>::BYTES + Geo<BN>::BYTES);
+  static bool attr_done = false;
+  auto kern = gemm_dma_kernel<BN, AL, BL, GATHER>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+      return -2;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1, zdim), dim3(NTH), smem, st, p);
+  const int rc = check_launch("gemm_dma_kernel");
+  return rc ? rc : 1;
+}
+
+template <int BN>
+int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st) {
+  const int al = d->a_layout, bl = d->b_layout, g = d->gather;
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BN, 0, 0, 0>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BN, 0, 0, 1>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BN, 0, 0, 2>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BN, 0, 1, 0>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BN, 1, 1, 0>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BN, 1, 1, 3>(p, zdim, st);
+  return 0;
+}
+
+int pick_bn(int N) {
+  if (N <= 64) return 64;
+  if (N <= 128) return 128;
+  const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;
+  return p192 <= p128 ? 192 : 128;
+}
+
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+// every byte offset the loaders form must stay below 2^31
+bool extents_ok(const HtrvtGemmDesc* d) {
+  const long long lim = (1ll << 31) - 64;
+  auto plain = [&](int layout, long long rows, long long ld) {
+    return layout == HTRVT_KMAJOR ? rows * ld * 2 : (long long)d->K * ld * 2;
+  };
+  long long a, b = plain(d->b_layout, d->N, d->ldb);
+  if (d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_WGRAD)
+    a = (long long)d->nB * d->Hi * d->Wi * d->Ci * 2;
+  else if (d->gather == HTRVT_GATHER_CONV_DGRAD)
+    a = (long long)d->nB * d->Ho * d->Wo * d->Co * 2;
+  else
+    a = plain(d->a_layout, d->M, d->lda);
+  return a < lim && b < lim;
+}
+
+}  // namespace
+
+namespace htrvt {
+
+int gemm_dma_num_mtiles(const HtrvtGemmDesc* d) {
+  if (d->dtype != HTRVT_BF16 || d->M <= 128) return -1;
+  return (d->M + BM - 1) / BM;
+}
+
+int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
+  if (d->dtype != HTRVT_BF16 || d->M <= 128 || !extents_ok(d)) return 0;
+  const int bn = pick_bn(d->N);
+  p.tiles_m = (d->M + BM - 1) / BM;
+  p.tiles_n = (d->N + bn - 1) / bn;
+  p.wo_shift = p.howo_shift = -1;
+  if (d->gather == HTRVT_GATHER_CONV_WGRAD) {
+    const int a = ilog2_exact(d->Wo), b = ilog2_exact(d->Ho * d->Wo);
+    if (a >= 0 && b >= 0) {
+      p.wo_shift = a;
+      p.howo_shift = b;
+    }
+  }
+  if (bn == 64) return dispatch<64>(d, p, zdim, st);
+  if (bn == 128) return dispatch<128>(d, p, zdim, st);
+  return dispatch<192>(d, p, zdim, st);
+}
+
+}  // namespace htrvt

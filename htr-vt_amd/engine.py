@@ -149,8 +149,9 @@ class Engine:
         return dx
 
     def _split_k(self, Mo, No, Kred):
-        tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
-        return int(max(1, min(1024 // max(tiles, 1), Kred // 512, 64)))
+        bm = 256 if self.dtype == torch.bfloat16 else 128
+        tiles = ((Mo + bm - 1) // bm) * ((No + 191) // 192)
+        return int(max(1, min(1024 // max(tiles, 1), Kred // 1024, 128)))
 
     def linear_wgrad(self, dy, x, dw, dbias):
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
@@ -183,10 +184,10 @@ class Engine:
     def conv_wgrad(self, dy, x, g: ConvGeom, dw):
         M = g.B * g.Ho * g.Wo
         cpi = cpad(g.Ci, self.dtype)
-        packed = self._zeros(g.Co, g.taps, cpi)
-        gemm(dy, x, packed, dtype=self.dtype, M=g.Co, N=g.taps * cpi, K=M, lda=g.Co, ldb=g.Ci, ldc=g.taps * cpi,
+        packed = self._zeros(g.taps, cpi, g.Co)
+        gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
              a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
-             split_k=self._split_k(g.Co, g.taps * cpi, M), accumulate=True, c_f32=True)
+             split_k=self._split_k(g.taps * cpi, g.Co, M), accumulate=True, c_f32=True)
         check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
 
     # ------------------------------------------------------------------ BatchNorm pieces

@@ -36,7 +36,7 @@ extern "C" {
 #define HTRVT_GATHER_NONE 0
 #define HTRVT_GATHER_CONV_FWD 1   /* A rows = output pixels, K = taps*Cpad(Ci)  */
 #define HTRVT_GATHER_CONV_DGRAD 2 /* A rows = input pixels,  K = taps*Cpad(Co)  */
-#define HTRVT_GATHER_CONV_WGRAD 3 /* B k = output pixels, N = taps*Cpad(Ci)     */
+#define HTRVT_GATHER_CONV_WGRAD 3 /* A = x gathered (MN-major, k = output pixel, M = taps*Cpad(Ci)), B = dy, N = Co */
 
 int htrvt_version(void);
 const char* htrvt_last_error(void);
@@ -161,7 +161,7 @@ int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, floa
 /* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */
 int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
                            int cpad_out, int dtype, void* stream);
-/* grad [Co][Ci][taps] += packed [Co][taps][cpad_in] */
+/* grad [Co][Ci][taps] += packed [taps][cpad_in][Co]  (the conv-wgrad GEMM output) */
 int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in, void* stream);
 int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 

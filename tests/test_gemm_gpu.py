@@ -24,7 +24,8 @@ def _ints(shape, lo=-3, hi=4, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 96), (384, 192, 256), (130, 72, 40), (256, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 96), (384, 192, 256), (130, 72, 40), (256, 2304, 768),
+                                   (1000, 264, 200), (512, 3072, 768)])
 def test_nt_plain_exact(dtype, M, N, K):
     ops = _ops()
     A, B = _ints((M, K), seed=1), _ints((N, K), seed=2)
@@ -109,6 +110,9 @@ def _pack_dgrad(w, cp):    # [Co,Ci,kh,kw] -> [Ci][taps][Cpad(Co)]
 
 
 CONVS = [  # B, Hi, Wi, Ci, Co, k, stride, pad
+    (2, 8, 256, 192, 192, 3, (1, 1), 1),      # layer1-like, exercises the 256x192 LDS-DMA tile
+    (2, 8, 128, 192, 384, 3, (2, 2), 1),
+    (2, 4, 128, 384, 768, 1, (2, 2), 0),
     (2, 8, 64, 16, 32, 3, (1, 1), 1),
     (2, 16, 64, 64, 64, 3, (2, 1), 1),
     (2, 8, 128, 64, 128, 3, (2, 2), 1),
@@ -149,8 +153,8 @@ def test_conv_fwd_dgrad_wgrad_exact(dtype, cfg):
              gather=ops.GATHER_CONV_DGRAD, geom=geom, Cpad=cpo)
     assert torch.equal(dxd.double().cpu(), x.grad.permute(0, 2, 3, 1).to(dtype).double())
     # wgrad (split-K, float32 atomics)
-    dwp = torch.zeros(Co, geom.taps, cpi, dtype=torch.float32, device="cuda")
-    ops.gemm(dyd, xd, dwp, dtype=dtype, M=Co, N=geom.taps * cpi, K=M, lda=Co, ldb=Ci, ldc=geom.taps * cpi,
+    dwp = torch.zeros(geom.taps, cpi, Co, dtype=torch.float32, device="cuda")
+    ops.gemm(xd, dyd, dwp, dtype=dtype, M=geom.taps * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co,
              a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi,
              split_k=3, accumulate=True, c_f32=True)
-    assert torch.equal(dwp.double().cpu(), _pack_fwd(w.grad, cpi))
+    assert torch.equal(dwp.double().cpu(), _pack_fwd(w.grad, cpi).permute(1, 2, 0))

@@ -207,6 +207,125 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 epilogue staged through LDS: accumulators -> (alpha, bias) -> bf16, written column-major into the dead
+// operand buffers; read back transposed (ds_read_b64_tr_b16) so that every lane owns 8 consecutive columns of
+// one row: GELU / GELU' / residual / pre-activation traffic and the C store are all 16-byte, row-contiguous.
+// (A per-lane 2-byte store epilogue is store-issue bound: 96 store instructions per wave for a 64x96 block.)
+// ---------------------------------------------------------------------------------------------
+constexpr int CST = BM * 2 + 8;  // bytes per staged column (256 rows + pad: conflict-free ds_write_b64)
+
+__device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <int TN, int BN>
+__device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
+                                                int wm, int wn, int tile_m, int lane, int wave, char* smem) {
+  const int h = lane >> 5, cl = lane & 31;
+  float cs1[TN], cs2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+  // ---- phase 1: registers -> LDS (column-major bf16) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ccol = (wn * TN + j) * 32 + cl;
+    const int n = n0 + ccol;
+    const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int crow = (wm * 2 + i) * 32 + 8 * g + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[i][j][4 * g + r];  // rows >= M and cols >= N hold exact zeros (zero-filled operands)
+          cs1[j] += a;
+          cs2[j] += a * a;
+          v[r] = a * p.alpha + bias;
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(smem + ccol * CST + crow * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: LDS -> (act / residual) -> global, 16 B per lane, 4 lanes = 64 contiguous bytes of one row ----
+  constexpr int GROUPS = BN / 32;             // groups of 4 chunks (32 columns) per row
+  constexpr int ITEMS = (BM / 16) * GROUPS;   // wave-level items: 16 rows x 32 columns
+  const int lr = lane & 15, lg = lane >> 4;
+  const int q = lr >> 2, pp = lr & 3;
+  typedef __attribute__((address_space(3))) s16x4_t* lptr;
+  for (int id = wave; id < ITEMS; id += 8) {
+    const int rbk = id / GROUPS, cg = id - rbk * GROUPS;
+    const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
+    const char* a0 = smem + (ccol0 + q) * CST + (crow0 + 4 * pp) * 2;
+    const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+    const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
+    const int m = m0 + crow0 + lr, n = n0 + ccol0;
+    if (m < p.M && n < p.N) {
+      const uint4 raw = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
+      float v[8] = {bf16lo(raw.x), bf16hi(raw.x), bf16lo(raw.y), bf16hi(raw.y),
+                    bf16lo(raw.z), bf16hi(raw.z), bf16lo(raw.w), bf16hi(raw.w)};
+      const long long o = coff + (long long)m * p.ldc + n;
+      bool touched = false;
+      if (p.act == 2) {
+        const uint4 pr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.preact) + o);
+        const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
+                            bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
+        touched = true;
+      } else if (p.preact != nullptr) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.preact) + o) = raw;
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        touched = true;
+      }
+      if (p.residual != nullptr) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + o);
+        v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
+        v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
+        touched = true;
+      }
+      uint4 out = raw;
+      if (touched) {
+        out.x = pack_bf16x2(v[0], v[1]);
+        out.y = pack_bf16x2(v[2], v[3]);
+        out.z = pack_bf16x2(v[4], v[5]);
+        out.w = pack_bf16x2(v[6], v[7]);
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o) = out;
+    }
+  }
+  if (p.colstats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem + BN * CST);  // [4 wm][BN][2], behind the staged tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
+      const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (h == 0) {
+        const int c = (wn * TN + j) * 32 + cl;
+        red[(wm * BN + c) * 2 + 0] = s1;
+        red[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN; c += NTH) {
+      const int n = n0 + c;
+      if (n < p.N) {
+        float* dst = p.colstats + (long long)tile_m * 2 * p.N;
+        dst[n] = (red[c * 2] + red[(BN + c) * 2]) + (red[(2 * BN + c) * 2] + red[(3 * BN + c) * 2]);
+        dst[p.N + n] = (red[c * 2 + 1] + red[(BN + c) * 2 + 1]) + (red[(2 * BN + c) * 2 + 1] + red[(3 * BN + c) * 2 + 1]);
+      }
+    }
+  }
+}
+
 template <int BN, int AL, int BL, int GATHER>
 __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
   using T = bf16_t;
@@ -288,7 +407,11 @@ __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
     __builtin_amdgcn_s_barrier();
   }
 
-  gemm_epilogue<T, TM, TN, 4, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
+  // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
+  if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
+    epilogue_staged<TN, BN>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem);
+  else
+    gemm_epilogue<T, TM, TN, 4, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
 }
 
 template <int BN, int AL, int BL, int GATHER>

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of htrvt_gemm on the shapes of the HTR-VT step (bf16, B=128, 64x1024).
+    python tools/bench_gemm.py [--iters 20]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import htrvt_amd  # noqa: E402
+from htrvt_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dt = torch.bfloat16
+    dev = "cuda"
+    rnd = lambda *s: (torch.rand(*s, device=dev) - 0.5).to(dt)  # noqa: E731
+    rows = []
+
+    def plain(tag, M, N, K, **kw):
+        a, b = rnd(M, K), rnd(N, K)
+        c = torch.empty(M, N, dtype=dt, device=dev)
+        ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw), args.iters)
+        rows.append((tag, ms, 2.0 * M * N * K))
+
+    def nn(tag, M, N, K):
+        a, b = rnd(M, K), rnd(K, N)
+        c = torch.empty(M, N, dtype=dt, device=dev)
+        ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_layout=ops.MNMAJOR), args.iters)
+        rows.append((tag, ms, 2.0 * M * N * K))
+
+    def tn(tag, M, N, K, split):
+        a, b = rnd(K, M), rnd(K, N)
+        c = torch.zeros(M, N, dtype=torch.float32, device=dev)
+        ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_layout=ops.MNMAJOR,
+                                     b_layout=ops.MNMAJOR, split_k=split, accumulate=True, c_f32=True), args.iters)
+        rows.append((tag, ms, 2.0 * M * N * K))
+
+    def conv(tag, B, Hi, Wi, Ci, Co, k, stride, pad):
+        g = ops.ConvGeom(B, Hi, Wi, Ci, Co, k, stride, pad)
+        M = B * g.Ho * g.Wo
+        x, y = rnd(B, Hi, Wi, Ci), torch.empty(B, g.Ho, g.Wo, Co, dtype=dt, device=dev)
+        wf, wd = rnd(Co, g.taps, Ci), rnd(Ci, g.taps, Co)
+        nmt = ops.gemm_num_mtiles(M, Co, dt, gather=ops.GATHER_CONV_FWD)
+        cs = torch.empty(nmt, 2, Co, dtype=torch.float32, device=dev)
+        fl = 2.0 * M * Co * g.taps * Ci
+        ms = timeit(lambda: ops.gemm(x, wf, y, dtype=dt, M=M, N=Co, K=g.taps * Ci, lda=Ci, ldb=g.taps * Ci, ldc=Co,
+                                     gather=ops.GATHER_CONV_FWD, geom=g, Cpad=Ci, colstats=cs), args.iters)
+        rows.append((tag + " fwd", ms, fl))
+        dx = torch.empty(B, Hi, Wi, Ci, dtype=dt, device=dev)
+        ms = timeit(lambda: ops.gemm(y, wd, dx, dtype=dt, M=B * Hi * Wi, N=Ci, K=g.taps * Co, lda=Co, ldb=g.taps * Co, ldc=Ci,
+                                     gather=ops.GATHER_CONV_DGRAD, geom=g, Cpad=Co), args.iters)
+        rows.append((tag + " dgrad", ms, fl))
+        dw = torch.zeros(g.taps, Ci, Co, dtype=torch.float32, device=dev)
+        tiles = ((g.taps * Ci + 255) // 256) * ((Co + 191) // 192)
+        split = max(1, min(1024 // tiles, M // 1024, 128))
+        ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
+                                     b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci, split_k=split,
+                                     accumulate=True, c_f32=True), args.iters)
+        rows.append((tag + f" wgrad(split {split})", ms, fl))
+
+    if not args.only or "plain" in args.only:
+        plain("NT 4096^3", 4096, 4096, 4096)
+        plain("NT 8192x8192x1024", 8192, 8192, 1024)
+        plain("NT qkv 32768x2304x768", 32768, 2304, 768)
+        plain("NT fc2 32768x768x3072", 32768, 768, 3072)
+        nn("NN dgrad-fc1 32768x768x3072", 32768, 768, 3072)
+        nn("NN dgrad-qkv 32768x768x2304", 32768, 768, 2304)
+        tn("TN wgrad-fc1 3072x768xK32768", 3072, 768, 32768, 16)
+    if not args.only or "conv" in args.only:
+        conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
+        conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
+        conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
+        conv("l2.0 192->384 s2 [128,8,1024]", 128, 8, 1024, 192, 384, 3, (2, 2), 1)
+    for tag, ms, fl in rows:
+        print(f"{tag:42s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("split_k", i32),
         ("nB", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32), ("Co", i32),
         ("kh", i32), ("kw", i32), ("sh", i32), ("sw", i32), ("ph", i32), ("pw", i32), ("Cpad", i32),
+        ("cls_h", i32), ("cls_w", i32),
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
         ("bias", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
         ("A", vp), ("B", vp), ("C", vp),

@@ -381,7 +381,11 @@ extern "C" int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d) {
 extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   HTRVT_REQUIRE(d != nullptr, "htrvt_gemm: null descriptor");
   HTRVT_REQUIRE(d->dtype == HTRVT_F32 || d->dtype == HTRVT_BF16, "htrvt_gemm: bad dtype %d", d->dtype);
-  HTRVT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "htrvt_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+  const bool cls = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0;
+  HTRVT_REQUIRE(d->M > 0 && d->N > 0 && (d->K > 0 || (cls && d->K == 0)), "htrvt_gemm: empty problem M=%d N=%d K=%d", d->M,
+                d->N, d->K);
+  HTRVT_REQUIRE(!cls || (d->dtype == HTRVT_BF16 && d->tile == 0 && d->cls_h < d->sh && d->cls_w >= 0 && d->cls_w < d->sw),
+                "htrvt_gemm: parity-class dgrad needs bfloat16 and 0 <= cls < stride");
   HTRVT_REQUIRE(d->A && d->B && d->C, "htrvt_gemm: null operand");
   const int ch = d->dtype == HTRVT_BF16 ? 8 : 4, bk = d->dtype == HTRVT_BF16 ? 64 : 32;
   // every 16-byte chunk must be fully inside or fully outside an operand row
@@ -402,7 +406,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
     if (d->gather == HTRVT_GATHER_CONV_FWD)
       HTRVT_REQUIRE(d->M == d->nB * d->Ho * d->Wo && d->K == taps * d->Cpad && d->N == d->Co && d->Cpad >= d->Ci,
                     "htrvt_gemm: conv fwd extents inconsistent");
-    if (d->gather == HTRVT_GATHER_CONV_DGRAD)
+    if (d->gather == HTRVT_GATHER_CONV_DGRAD && !cls)
       HTRVT_REQUIRE(d->M == d->nB * d->Hi * d->Wi && d->K == taps * d->Cpad && d->N == d->Ci && d->Cpad >= d->Co,
                     "htrvt_gemm: conv dgrad extents inconsistent");
     if (d->gather == HTRVT_GATHER_CONV_WGRAD)
@@ -439,6 +443,23 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;
+  p.cls_h = p.cls_w = -1;
+  p.Hq = d->Hi; p.Wq = d->Wi;
+  p.ntapsel = d->kh * d->kw;
+  for (int t = 0; t < 12; ++t) p.tapsel[t] = (unsigned char)t;
+  if (cls) {  // taps (dy,dx) that reach pixels of this class: (cls + pad - d) divisible by the stride
+    p.cls_h = d->cls_h; p.cls_w = d->cls_w;
+    p.Hq = (d->Hi - d->cls_h + d->sh - 1) / d->sh;
+    p.Wq = (d->Wi - d->cls_w + d->sw - 1) / d->sw;
+    p.ntapsel = 0;
+    for (int dy = 0; dy < d->kh; ++dy)
+      for (int dx = 0; dx < d->kw; ++dx)
+        if ((d->cls_h + d->ph - dy) % d->sh == 0 && (d->cls_w + d->pw - dx) % d->sw == 0)
+          p.tapsel[p.ntapsel++] = (unsigned char)(dy * d->kw + dx);
+    HTRVT_REQUIRE(d->M == d->nB * p.Hq * p.Wq && d->K == p.ntapsel * d->Cpad && d->N == d->Ci,
+                  "htrvt_gemm: parity-class dgrad extents inconsistent (expected M=%d K=%d)", d->nB * p.Hq * p.Wq,
+                  p.ntapsel * d->Cpad);
+  }
   const int zdim = p.split_k > 1 ? p.split_k : (d->batch > 1 ? d->batch : 1);
   HTRVT_REQUIRE((long long)p.tiles_m * p.tiles_n < (1ll << 31) && zdim < 65536, "htrvt_gemm: grid too large");
   hipStream_t st = (hipStream_t)stream;
@@ -447,6 +468,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
     const int r = gemm_dma_try_launch(d, q, zdim, st);
     if (r != 0) return r < 0 ? r : 0;
   }
+  HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");
   if (d->dtype == HTRVT_BF16) {
     if (bn == 64) return dispatch_layout<bf16_t, 128, 64>(d, p, zdim, st);
     if (bn == 128) return dispatch_layout<bf16_t, 128, 128>(d, p, zdim, st);

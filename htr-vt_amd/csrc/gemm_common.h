@@ -40,6 +40,10 @@ struct KParams {
   float* colstats;
   int tiles_m, tiles_n;
   int wo_shift, howo_shift;  // log2(Wo), log2(Ho*Wo) when powers of two, else -1 (conv-wgrad pixel decode)
+  // strided conv-dgrad by input-pixel parity class: rows are the pixels (hi % sh == cls_h, wi % sw == cls_w),
+  // K runs over the class's valid taps only (tapsel); cls_h < 0: all pixels, all taps
+  int cls_h, cls_w, Hq, Wq, ntapsel;
+  unsigned char tapsel[12];
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

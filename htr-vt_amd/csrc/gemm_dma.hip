@@ -108,10 +108,14 @@ struct DmaLoader {
           off0[i] = (unsigned)b * p.Hi * p.Wi * p.Ci * 2;
           c0[i] = ho * p.sh - p.ph;
           c1[i] = wo * p.sw - p.pw;
-        } else {
-          const int hw = p.Hi * p.Wi;
+        } else {  // input pixel of this row (all pixels, or the pixels of one stride-parity class)
+          const int hw = p.Hq * p.Wq;
           const int b = row / hw, r = row - b * hw;
-          const int hi = r / p.Wi, wi = r - hi * p.Wi;
+          int hi = r / p.Wq, wi = r - hi * p.Wq;
+          if (p.cls_h >= 0) {
+            hi = hi * p.sh + p.cls_h;
+            wi = wi * p.sw + p.cls_w;
+          }
           off0[i] = (unsigned)b * p.Ho * p.Wo * p.Co * 2;
           c0[i] = hi + p.ph;
           c1[i] = wi + p.pw;
@@ -139,13 +143,17 @@ struct DmaLoader {
     }
   }
 
+  // kmap: plain K-major operand (the packed conv weights) whose k runs over a SELECTED tap list
+  template <bool KMAP = false>
   __device__ __forceinline__ void issue(const KParams& p, unsigned lds_tile, int k0, int kend, int wave) {
     int tap_dy = 0, tap_dx = 0, cbase = k0;
-    if constexpr (ROLE == 1 || ROLE == 2) {
-      const int tap = k0 / p.Cpad;
-      cbase = k0 - tap * p.Cpad;
+    if constexpr (ROLE == 1 || ROLE == 2 || KMAP) {
+      const int ti = k0 / p.Cpad;
+      const int tap = p.tapsel[ti];
+      cbase = k0 - ti * p.Cpad;
       tap_dy = tap / p.kw;
       tap_dx = tap - tap_dy * p.kw;
+      if constexpr (KMAP) cbase += tap * p.Cpad;  // column of the packed weight matrix
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -154,7 +162,7 @@ struct DmaLoader {
       if constexpr (LAYOUT == HTRVT_KMAJOR) {
         if constexpr (ROLE == 0) {
           v = v && (k0 + c2[i] < kend);
-          off += (unsigned)k0 * 2;
+          off += (unsigned)(KMAP ? cbase : k0) * 2;
         } else if constexpr (ROLE == 1) {
           const int hi = c0[i] + tap_dy, wi = c1[i] + tap_dx, c = cbase + c2[i];
           v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi) && (c < p.Ci);
@@ -264,8 +272,15 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
     const char* a0 = smem + (ccol0 + q) * CST + (crow0 + 4 * pp) * 2;
     const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
     const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
-    const int m = m0 + crow0 + lr, n = n0 + ccol0;
+    int m = m0 + crow0 + lr;
+    const int n = n0 + ccol0;
     if (m < p.M && n < p.N) {
+      if (p.cls_h >= 0) {  // class row -> input-pixel row of the NHWC gradient
+        const int hw = p.Hq * p.Wq;
+        const int b = m / hw, r = m - b * hw;
+        const int hq = r / p.Wq, wq = r - hq * p.Wq;
+        m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
+      }
       const uint4 raw = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
       float v[8] = {bf16lo(raw.x), bf16hi(raw.x), bf16lo(raw.y), bf16hi(raw.y),
                     bf16lo(raw.z), bf16hi(raw.z), bf16lo(raw.w), bf16hi(raw.w)};
@@ -374,9 +389,10 @@ __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const unsigned lds0 = lds_addr_of(smem);
+  constexpr bool KMAP = (GATHER == 1 || GATHER == 2);
   if (nkt > 0) {
     la.issue(p, lds0, kbeg, kend, wave);
-    lb.issue(p, lds0 + A_BYTES, kbeg, kend, wave);
+    lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, wave);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
     const unsigned nxt = lds0 + ((kt + 1) & 1) * STAGE;
     if (kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
       la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, wave);
-      lb.issue(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, wave);
+      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, wave);
     }
     const char* sa = cur;
     const char* sb = cur + A_BYTES;

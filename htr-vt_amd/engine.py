@@ -149,9 +149,21 @@ class Engine:
         return dx
 
     def _split_k(self, Mo, No, Kred):
-        bm = 256 if self.dtype == torch.bfloat16 else 128
-        tiles = ((Mo + bm - 1) // bm) * ((No + 191) // 192)
-        return int(max(1, min(1024 // max(tiles, 1), Kred // 1024, 128)))
+        """split-K factor of a weight-gradient GEMM: fill the 256 CUs in whole rounds, but keep the float32
+        atomic traffic (one full output tile per block, ~1.3 TB/s chip-wide) small against the MFMA time."""
+        bm, bn = (256, 192) if self.dtype == torch.bfloat16 else (128, 128)
+        tiles = ((Mo + bm - 1) // bm) * ((No + bn - 1) // bn)
+        flops = 2.0 * Mo * No * Kred
+        best, best_t = 1, None
+        for s in range(1, 129):
+            if Kred // s < 512:
+                break
+            blocks = tiles * s
+            rounds = (blocks + 255) // 256
+            t = flops / 1.0e15 * (rounds * 256.0 / blocks) + blocks * bm * bn * 4 / 1.3e12
+            if best_t is None or t < best_t:
+                best, best_t = s, t
+        return best
 
     def linear_wgrad(self, dy, x, dw, dbias):
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
@@ -177,6 +189,16 @@ class Engine:
     def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None):
         cpo = cpad(g.Co, self.dtype)
         dx = self._empty(g.B, g.Hi, g.Wi, g.Ci)
+        if self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128:
+            # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
+            for a in range(g.sh):
+                for b in range(g.sw):
+                    nt = sum(1 for dy in range(g.kh) if (a + g.ph - dy) % g.sh == 0) * \
+                         sum(1 for dx_ in range(g.kw) if (b + g.pw - dx_) % g.sw == 0)
+                    Hq, Wq = (g.Hi - a + g.sh - 1) // g.sh, (g.Wi - b + g.sw - 1) // g.sw
+                    gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
+                         ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b))
+            return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual)
         return dx

@@ -64,7 +64,7 @@ class ConvGeom:
 def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
          Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
          accumulate=False, bias=None, preact=None, residual=None, colstats=None, tile=0,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, cls=None):
     """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
     is used); *_off are element offsets into them."""
     d = GemmDesc()
@@ -77,6 +77,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.sB_o, d.sB_i = sB
     d.sC_o, d.sC_i = sC
     d.split_k = split_k
+    d.cls_h, d.cls_w = (-1, -1) if cls is None else cls
     if geom is not None:
         geom.fill(d)
         d.Cpad = Cpad
@@ -103,6 +104,8 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     e1.record()
     if geom is None:
         flops = 2.0 * M * N * K * max(batch, 1)
+    elif cls is not None:   # one parity class of a strided dgrad: only its useful MACs
+        flops = 2.0 * M * N * (K // Cpad) * geom.Co
     else:   # algorithmic FLOPs of the convolution, whichever of fwd/dgrad/wgrad this launch is
         flops = 2.0 * geom.B * geom.Ho * geom.Wo * geom.Co * geom.taps * geom.Ci
     key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1))

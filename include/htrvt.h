@@ -56,6 +56,10 @@ typedef struct HtrvtGemmDesc {
   int32_t split_k;          /* >1: grid.z splits K, result accumulated (needs accumulate=1, c_f32=1) */
   /* conv geometry (gather != 0) */
   int32_t nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
+  /* HTRVT_GATHER_CONV_DGRAD of a strided conv, one launch per input-pixel parity class (bfloat16 only):
+   * cls_h/cls_w in [0,sh)/[0,sw) select the pixels hi%sh==cls_h, wi%sw==cls_w (M = their count, row-major over
+   * (b, hi/sh, wi/sw)); K = (#taps that can reach this class) * Cpad (may be 0).  cls_h = -1: all pixels/taps. */
+  int32_t cls_h, cls_w;
   /* epilogue */
   float alpha;
   int32_t act;              /* 0 none, 1 exact-erf GELU                              */

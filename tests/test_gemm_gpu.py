@@ -152,6 +152,20 @@ def test_conv_fwd_dgrad_wgrad_exact(dtype, cfg):
     ops.gemm(dyd, wd, dxd, dtype=dtype, M=Bn * Hi * Wi, N=Ci, K=geom.taps * cpo, lda=Co, ldb=geom.taps * cpo, ldc=Ci,
              gather=ops.GATHER_CONV_DGRAD, geom=geom, Cpad=cpo)
     assert torch.equal(dxd.double().cpu(), x.grad.permute(0, 2, 3, 1).to(dtype).double())
+    # strided dgrad again, one launch per input-pixel parity class (bf16 LDS-DMA kernel only)
+    sh, sw = stride
+    if dtype == torch.bfloat16 and stride != (1, 1) and Bn * Hi * Wi // (sh * sw) > 128:
+        res = _ints((Bn, Hi, Wi, Ci), -2, 3, seed=13)
+        dx2 = torch.full((Bn, Hi, Wi, Ci), 7.0, dtype=dtype, device="cuda")
+        for a in range(sh):
+            for b in range(sw):
+                nt = sum(1 for dy_ in range(k) if (a + pad - dy_) % sh == 0) * sum(1 for dx_ in range(k) if (b + pad - dx_) % sw == 0)
+                Hq, Wq = (Hi - a + sh - 1) // sh, (Wi - b + sw - 1) // sw
+                ops.gemm(dyd, wd, dx2, dtype=dtype, M=Bn * Hq * Wq, N=Ci, K=nt * cpo, lda=Co, ldb=geom.taps * cpo, ldc=Ci,
+                         gather=ops.GATHER_CONV_DGRAD, geom=geom, Cpad=cpo, cls=(a, b), residual=res.to(dtype).cuda())
+        # the staged bf16 epilogue adds the residual to the bf16-rounded product (documented double rounding)
+        want = (x.grad.permute(0, 2, 3, 1).to(dtype).double() + res).to(dtype).double()
+        assert torch.equal(dx2.double().cpu(), want)
     # wgrad (split-K, float32 atomics)
     dwp = torch.zeros(geom.taps, cpi, Co, dtype=torch.float32, device="cuda")
     ops.gemm(xd, dyd, dwp, dtype=dtype, M=geom.taps * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co,

@@ -1,0 +1,138 @@
+"""CPU-only checks of the host side: the C ABI library loads and exports every symbol
+declared in include/htrvt.h, the drop-in module reproduces the reference's
+construction (state_dict contract, seed-123 init bit for bit), refuses to run
+without a GPU (no fallback), and the data-parallel gradient buckets reduce
+correctly across two gloo ranks."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import ctypes
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "htrvt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(htrvt_\w+)\s*\(", hdr))
+    assert len(declared) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in include/htrvt.h but not exported"
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == declared
+    assert _lib.lib.htrvt_version() >= 100
+
+
+def test_create_model_matches_reference_init(golden_dir):
+    from htrvt_amd.model import HTR_VT
+    g = np.load(os.path.join(golden_dir, "create_model_init.npz"), allow_pickle=False)
+    torch.manual_seed(123)
+    m = HTR_VT.create_model(nb_cls=80, img_size=[64, 512])
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    abss = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    assert np.array_equal(sums, g["sums"]) and np.array_equal(abss, g["abssums"])   # same RNG stream, same bits
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"]) == 53486096
+    assert m.embed_dim == 768 and m.num_patches == 128
+    assert not m.pos_embed.requires_grad and m.mask_token.requires_grad
+    with pytest.raises(TypeError):                     # duplicate kwargs fail exactly as in the reference
+        HTR_VT.create_model(80, [64, 512], embed_dim=256)
+
+
+def test_no_cpu_fallback():
+    from htrvt_amd.model import HTR_VT
+    m = HTR_VT.create_model(nb_cls=80, img_size=[64, 512])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 1, 64, 512))
+    with pytest.raises(RuntimeError):
+        m.patch_embed(torch.zeros(1, 1, 64, 512))      # sub-modules only own parameters
+
+
+def test_span_mask_uses_reference_rng_stream(golden_dir):
+    from htrvt_amd.model import HTR_VT
+    g = np.load(os.path.join(golden_dir, "tiny_model.npz"), allow_pickle=False)
+    m = HTR_VT.create_model(nb_cls=80, img_size=[64, 512])
+    torch.manual_seed(11)
+    keep = m.generate_span_mask(128, 0.4, 8)
+    assert np.array_equal(keep.numpy(), g["keep_mask"])
+
+
+def test_ema_deepcopy_and_state_dict_roundtrip():
+    import copy
+    from htrvt_amd.model import HTR_VT
+    torch.manual_seed(0)
+    m = HTR_VT.create_model(nb_cls=80, img_size=[64, 512])
+    ema = copy.deepcopy(m)                               # utils.ModelEma (utils.py:130)
+    assert ema._engines == {} and ema is not m
+    sd = {("module." + k): v for k, v in m.state_dict().items()}
+    stripped = {k[len("module."):]: v for k, v in sd.items()}   # test.py:30-40
+    ema.load_state_dict(stripped, strict=True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from htrvt_amd.model import HTR_VT
+        from htrvt_amd.trainer import FlatParams
+        torch.manual_seed(100 + rank)                     # ranks start DIFFERENT: broadcast must fix it
+        m = HTR_VT.MaskedAutoencoderViT(80, img_size=[64, 512], patch_size=(4, 64), embed_dim=64, depth=2, num_heads=2,
+                                        mlp_ratio=4, norm_layer=torch.nn.LayerNorm)
+        fp = FlatParams(m, world_size=world)
+        fp.check_views()
+        # every rank holds rank-0's parameters now
+        ref = fp.flat_p.clone()
+        dist.broadcast(ref, 0)
+        same_params = bool(torch.equal(ref, fp.flat_p))
+        # gradients: rank r writes (r+1)/world * g0 (the 1/world factor is what the CTC kernel's grad_scale applies)
+        g0 = torch.arange(fp.flat_g.numel(), dtype=torch.float32) % 97 - 48
+        for n, g in fp.G.items():
+            g.copy_((rank + 1) / world * torch.ones_like(g))
+        fp.flat_g.mul_(g0)
+        fp.reduce_encoder_bucket()
+        fp.reduce_stem_bucket()
+        want = sum((r + 1) / world for r in range(world)) * g0
+        pad_free = torch.zeros_like(want, dtype=torch.bool)
+        for n, g in fp.G.items():
+            off = (g.data_ptr() - fp.flat_g.data_ptr()) // 4
+            pad_free[off:off + g.numel()] = True
+        ok = bool(torch.allclose(fp.flat_g[pad_free], want[pad_free], rtol=1e-6, atol=1e-6))
+        names = [n for n, _ in m.named_parameters() if _.requires_grad]
+        first_enc = names.index("blocks.0.norm1.weight")
+        enc_ok = all(n.startswith(("blocks.", "norm.", "head.")) for n in names[first_enc:]) and \
+            not any(n.startswith(("blocks.", "norm.", "head.")) for n in names[:first_enc])
+        out[rank] = (same_params, ok, enc_ok, int(fp.enc_start))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_gradient_buckets_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        same_params, ok, enc_ok, enc_start = res[r]
+        assert same_params and ok and enc_ok and enc_start > 0
+    assert res[0][3] == res[1][3]

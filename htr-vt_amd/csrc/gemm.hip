@@ -62,7 +62,7 @@ struct Loader {
         const int rl = (tid >> 3) + 32 * i, chunk = tid & 7;
         const int row = row0 + rl;
         ok[i] = row < rows_total;
-        ldsoff[i] = rl * 128 + ((chunk ^ (rl & 7)) << 4);
+        ldsoff[i] = rl * 128 + ((chunk ^ ((rl >> 1) & 7)) << 4);
         c2[i] = chunk * CH;  // k offset of this chunk inside a k-tile
         if constexpr (ROLE == 0) {
           ptr[i] = base + ((long long)row * ld + chunk * CH) * SZ;
@@ -165,7 +165,7 @@ __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int rb, int s, in
   if constexpr (LAYOUT == HTRVT_KMAJOR) {
     const int row = rb * 32 + (lane & 31);
     const int chunk = 2 * s + (lane >> 5);
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
@@ -189,7 +189,7 @@ __device__ __forceinline__ float4 frag_f32(const char* lds, int rb, int u, int l
   if constexpr (LAYOUT == HTRVT_KMAJOR) {
     const int row = rb * 32 + (lane & 31);
     const int chunk = 2 * u + h;
-    return *reinterpret_cast<const float4*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    return *reinterpret_cast<const float4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
   } else {
     const char* a = lds + (8 * u + 4 * h) * G::STRIDE + (rb * 32 + (lane & 31)) * 4;
     float4 r;
@@ -347,7 +347,7 @@ int dispatch_layout(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStrea
 
 int pick_tile(const HtrvtGemmDesc* d, int* bm, int* bn) {
   *bm = 128;
-  if (d->tile != 0) {
+  if (d->tile >= 1000) {
     *bm = d->tile / 1000;
     *bn = d->tile % 1000;
   } else if (d->N <= 64) {
@@ -369,7 +369,7 @@ int pick_tile(const HtrvtGemmDesc* d, int* bm, int* bn) {
 }  // namespace
 
 extern "C" int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d) {
-  if (d->dtype == HTRVT_BF16 && d->tile == 0) {
+  if (d->dtype == HTRVT_BF16 && d->tile != 1) {
     const int r = gemm_dma_num_mtiles(d);
     if (r > 0) return r;
   }
@@ -384,7 +384,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   const bool cls = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0;
   HTRVT_REQUIRE(d->M > 0 && d->N > 0 && (d->K > 0 || (cls && d->K == 0)), "htrvt_gemm: empty problem M=%d N=%d K=%d", d->M,
                 d->N, d->K);
-  HTRVT_REQUIRE(!cls || (d->dtype == HTRVT_BF16 && d->tile == 0 && d->cls_h < d->sh && d->cls_w >= 0 && d->cls_w < d->sw),
+  HTRVT_REQUIRE(!cls || (d->dtype == HTRVT_BF16 && d->tile != 1 && d->cls_h < d->sh && d->cls_w >= 0 && d->cls_w < d->sw),
                 "htrvt_gemm: parity-class dgrad needs bfloat16 and 0 <= cls < stride");
   HTRVT_REQUIRE(d->A && d->B && d->C, "htrvt_gemm: null operand");
   const int ch = d->dtype == HTRVT_BF16 ? 8 : 4, bk = d->dtype == HTRVT_BF16 ? 64 : 32;
@@ -463,7 +463,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   const int zdim = p.split_k > 1 ? p.split_k : (d->batch > 1 ? d->batch : 1);
   HTRVT_REQUIRE((long long)p.tiles_m * p.tiles_n < (1ll << 31) && zdim < 65536, "htrvt_gemm: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == HTRVT_BF16 && d->tile == 0) {  // throughput path: LDS-DMA staged 256-row tiles (gemm_dma.hip)
+  if (d->dtype == HTRVT_BF16 && d->tile != 1) {  // throughput path: LDS-DMA staged 256-row tiles (gemm_dma.hip)
     KParams q = p;
     const int r = gemm_dma_try_launch(d, q, zdim, st);
     if (r != 0) return r < 0 ? r : 0;

@@ -11,7 +11,8 @@
 //
 // LDS images (DMA writes lane-linear: base + 16*lane, so any swizzle is applied to
 // the per-lane SOURCE chunk and again on the read):
-//   K-major operand  : [rows][128 B], 16-byte chunk c stored at c ^ (row & 7)     -> ds_read_b128, conflict-free
+//   K-major operand  : [rows][128 B], 16-byte chunk c stored at c ^ ((row>>1) & 7) -> ds_read_b128, conflict-free
+//                      (two 128-B rows share a 256-B bank line: the 16 rows of a ds_read_b128 lane group hit 16 slots)
 //   MN-major operand : [64 k][rows*2 B], chunk c stored at (c + 4*(k&3)) mod CPR  -> ds_read_b64_tr_b16 (transpose)
 #include "gemm_common.h"
 
@@ -19,8 +20,6 @@ using namespace htrvt;
 
 namespace {
 
-constexpr int NTH = 512;
-constexpr int BM = 256;
 constexpr int BK = 64;
 constexpr unsigned OOB = 0x80000000u;
 
@@ -47,10 +46,10 @@ __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
 
-template <int ROWS>
+template <int ROWS, int NWAVES = 8>
 struct Geo {
   static constexpr int BYTES = ROWS * 128;      // both layouts: ROWS * 64 k * 2 B
-  static constexpr int NP = ROWS / 64;          // 1-KiB DMA pieces per wave per k-tile
+  static constexpr int NP = ROWS / 8 / NWAVES;  // 1-KiB DMA pieces per wave per k-tile
   static constexpr int CPR_MN = ROWS / 8;       // 16-byte chunks per k-row of an MN-major tile
   static constexpr int ROT = (ROWS >= 128) ? 4 : 0;
 };
@@ -71,27 +70,32 @@ __device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int&
 }
 
 // ROLE: 0 plain, 1 conv-fwd rows, 2 conv-dgrad rows (K-major), 3 conv-wgrad (MN-major, k = output pixel)
-template <int ROWS, int LAYOUT, int ROLE>
+template <int ROWS, int LAYOUT, int ROLE, int NWAVES>
 struct DmaLoader {
-  using G = Geo<ROWS>;
+  using G = Geo<ROWS, NWAVES>;
   static constexpr int NP = G::NP;
   unsigned off0[NP];
   int c0[NP], c1[NP], c2[NP];
   bool ok[NP];
   i32x4_t rsrc;
   unsigned ld2;  // leading dimension in bytes
+  // conv row gather: byte offset of (pixel reached through the current tap, this lane's chunk) or OOB -- refreshed
+  // only when the k-loop enters a new tap, so a k-tile inside a tap costs one add per piece
+  unsigned tapoff[NP];
+  int cur_ti;
 
   __device__ __forceinline__ void init(const KParams& p, const char* base, long long ld, int row0, int rows_total, int wave,
                                        int lane) {
     const unsigned long long ba = (unsigned long long)base;  // raw buffer, stride 0, 2 GiB of records
     rsrc = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
     ld2 = (unsigned)(ld * 2);
+    cur_ti = -1;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int pi = wave + 8 * i;
+      const int pi = wave + NWAVES * i;
       if constexpr (LAYOUT == HTRVT_KMAJOR) {
         const int rl = pi * 8 + (lane >> 3);
-        const int cg = (lane & 7) ^ (rl & 7);
+        const int cg = (lane & 7) ^ ((rl >> 1) & 7);
         const int row = row0 + rl;
         ok[i] = row < rows_total;
         c2[i] = cg * 8;
@@ -154,6 +158,28 @@ struct DmaLoader {
       tap_dy = tap / p.kw;
       tap_dx = tap - tap_dy * p.kw;
       if constexpr (KMAP) cbase += tap * p.Cpad;  // column of the packed weight matrix
+      if constexpr (ROLE == 1 || ROLE == 2) {
+        if (ti != cur_ti) {  // wave-uniform: entering a new tap
+          cur_ti = ti;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            bool v = ok[i];
+            unsigned off = off0[i];
+            if constexpr (ROLE == 1) {
+              const int hi = c0[i] + tap_dy, wi = c1[i] + tap_dx;
+              v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+              off += (unsigned)((hi * p.Wi + wi) * p.Ci + c2[i]) * 2;
+            } else {
+              const int th = c0[i] - tap_dy, tw = c1[i] - tap_dx;
+              const int ho = th >> (p.sh - 1), wo = tw >> (p.sw - 1);
+              v = v && (th >= 0) && (tw >= 0) && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0) && (ho < p.Ho) &&
+                  (wo < p.Wo);
+              off += (unsigned)((ho * p.Wo + wo) * p.Co + c2[i]) * 2;
+            }
+            tapoff[i] = v ? off : OOB;
+          }
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -163,16 +189,10 @@ struct DmaLoader {
         if constexpr (ROLE == 0) {
           v = v && (k0 + c2[i] < kend);
           off += (unsigned)(KMAP ? cbase : k0) * 2;
-        } else if constexpr (ROLE == 1) {
-          const int hi = c0[i] + tap_dy, wi = c1[i] + tap_dx, c = cbase + c2[i];
-          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi) && (c < p.Ci);
-          off += (unsigned)((hi * p.Wi + wi) * p.Ci + c) * 2;
-        } else {
-          const int th = c0[i] - tap_dy, tw = c1[i] - tap_dx, c = cbase + c2[i];
-          const int ho = th >> (p.sh - 1), wo = tw >> (p.sw - 1);
-          v = v && (th >= 0) && (tw >= 0) && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0) && (ho < p.Ho) &&
-              (wo < p.Wo) && (c < p.Co);
-          off += (unsigned)((ho * p.Wo + wo) * p.Co + c) * 2;
+        } else {  // ROLE 1 / 2: cached tap offset + channel offset; an OOB base stays OOB (adds < 2^16)
+          const int cvalid = ROLE == 1 ? p.Ci : p.Co;
+          v = (cbase + c2[i] < cvalid);
+          off = tapoff[i] + (unsigned)cbase * 2;
         }
       } else {
         const int k = k0 + c2[i];
@@ -188,7 +208,7 @@ struct DmaLoader {
         }
       }
       const unsigned voff = v ? off : OOB;
-      dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_tile + (wave + 8 * i) * 1024), voff);
+      dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_tile + (wave + NWAVES * i) * 1024), voff);
     }
   }
 };
@@ -199,7 +219,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, in
   if constexpr (LAYOUT == HTRVT_KMAJOR) {
     const int row = rb * 32 + (lane & 31);
     const int chunk = 2 * s + (lane >> 5);
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
@@ -221,14 +241,19 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, in
 // one row: GELU / GELU' / residual / pre-activation traffic and the C store are all 16-byte, row-contiguous.
 // (A per-lane 2-byte store epilogue is store-issue bound: 96 store instructions per wave for a 64x96 block.)
 // ---------------------------------------------------------------------------------------------
-constexpr int CST = BM * 2 + 8;  // bytes per staged column (256 rows + pad: conflict-free ds_write_b64)
+template <int BM>
+struct Stg {
+  static constexpr int CST = BM * 2 + 8;  // bytes per staged column (BM rows + pad: conflict-free ds_write_b64)
+};
 
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <int TN, int BN>
+template <int TN, int BN, int BM>
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem) {
+  constexpr int CST = Stg<BM>::CST;
+  constexpr int NWAVES = BM / 32, NTH = BM * 2, NWM = BM / 64;
   const int h = lane >> 5, cl = lane & 31;
   float cs1[TN], cs2[TN];
 #pragma unroll
@@ -266,7 +291,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   const int lr = lane & 15, lg = lane >> 4;
   const int q = lr >> 2, pp = lr & 3;
   typedef __attribute__((address_space(3))) s16x4_t* lptr;
-  for (int id = wave; id < ITEMS; id += 8) {
+  for (int id = wave; id < ITEMS; id += NWAVES) {
     const int rbk = id / GROUPS, cg = id - rbk * GROUPS;
     const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
     const char* a0 = smem + (ccol0 + q) * CST + (crow0 + 4 * pp) * 2;
@@ -318,7 +343,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
     }
   }
   if (p.colstats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + BN * CST);  // [4 wm][BN][2], behind the staged tile
+    float* red = reinterpret_cast<float*>(smem + BN * CST);  // [NWM][BN][2], behind the staged tile
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
@@ -334,16 +359,23 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
       const int n = n0 + c;
       if (n < p.N) {
         float* dst = p.colstats + (long long)tile_m * 2 * p.N;
-        dst[n] = (red[c * 2] + red[(BN + c) * 2]) + (red[(2 * BN + c) * 2] + red[(3 * BN + c) * 2]);
-        dst[p.N + n] = (red[c * 2 + 1] + red[(BN + c) * 2 + 1]) + (red[(2 * BN + c) * 2 + 1] + red[(3 * BN + c) * 2 + 1]);
+        float a = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) {
+          a += red[(w * BN + c) * 2];
+          q2 += red[(w * BN + c) * 2 + 1];
+        }
+        dst[n] = a;
+        dst[p.N + n] = q2;
       }
     }
   }
 }
 
-template <int BN, int AL, int BL, int GATHER>
-__global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
+template <int BM, int BN, int AL, int BL, int GATHER>
+__global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
   using T = bf16_t;
+  constexpr int NTH = BM * 2, NWAVES = BM / 32;
   constexpr int TM = 2, TN = BN / 64;
   constexpr int A_BYTES = Geo<BM>::BYTES, B_BYTES = Geo<BN>::BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -374,8 +406,8 @@ __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  DmaLoader<BM, AL, GATHER> la;
-  DmaLoader<BN, BL, 0> lb;
+  DmaLoader<BM, AL, GATHER, NWAVES> la;
+  DmaLoader<BN, BL, 0, NWAVES> lb;
   la.init(p, Ab, p.lda, m0, p.M, wave, lane);
   lb.init(p, Bb, p.ldb, n0, p.N, wave, lane);
 
@@ -425,16 +457,17 @@ __global__ __launch_bounds__(NTH) void gemm_dma_kernel(const KParams p) {
 
   // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
   if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem);
+    epilogue_staged<TN, BN, BM>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem);
   else
-    gemm_epilogue<T, TM, TN, 4, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
+    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
 }
 
-template <int BN, int AL, int BL, int GATHER>
+template <int BM, int BN, int AL, int BL, int GATHER>
 int launch(const KParams& p, int zdim, hipStream_t st) {
+  constexpr int NTH = BM * 2;
   constexpr int smem = 2 * (Geo<BM>::BYTES + Geo<BN>::BYTES);
   static bool attr_done = false;
-  auto kern = gemm_dma_kernel<BN, AL, BL, GATHER>;
+  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -448,16 +481,22 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
   return rc ? rc : 1;
 }
 
-template <int BN>
+template <int BM, int BN>
 int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st) {
   const int al = d->a_layout, bl = d->b_layout, g = d->gather;
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BN, 0, 0, 0>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BN, 0, 0, 1>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BN, 0, 0, 2>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BN, 0, 1, 0>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BN, 1, 1, 0>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BN, 1, 1, 3>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3>(p, zdim, st);
   return 0;
+}
+
+int pick_bm(const HtrvtGemmDesc* d) {
+  if (d->tile == 2) return 128;
+  if (d->tile == 3) return 256;
+  return 256;
 }
 
 int pick_bn(int N) {
@@ -495,14 +534,15 @@ bool extents_ok(const HtrvtGemmDesc* d) {
 namespace htrvt {
 
 int gemm_dma_num_mtiles(const HtrvtGemmDesc* d) {
-  if (d->dtype != HTRVT_BF16 || d->M <= 128) return -1;
-  return (d->M + BM - 1) / BM;
+  if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1) return -1;
+  const int bm = pick_bm(d);
+  return (d->M + bm - 1) / bm;
 }
 
 int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
-  if (d->dtype != HTRVT_BF16 || d->M <= 128 || !extents_ok(d)) return 0;
-  const int bn = pick_bn(d->N);
-  p.tiles_m = (d->M + BM - 1) / BM;
+  if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1 || !extents_ok(d)) return 0;
+  const int bn = pick_bn(d->N), bm = pick_bm(d);
+  p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;
   if (d->gather == HTRVT_GATHER_CONV_WGRAD) {
@@ -512,9 +552,14 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.howo_shift = b;
     }
   }
-  if (bn == 64) return dispatch<64>(d, p, zdim, st);
-  if (bn == 128) return dispatch<128>(d, p, zdim, st);
-  return dispatch<192>(d, p, zdim, st);
+  if (bm == 128) {
+    if (bn == 64) return dispatch<128, 64>(d, p, zdim, st);
+    if (bn == 128) return dispatch<128, 128>(d, p, zdim, st);
+    return dispatch<128, 192>(d, p, zdim, st);
+  }
+  if (bn == 64) return dispatch<256, 64>(d, p, zdim, st);
+  if (bn == 128) return dispatch<256, 128>(d, p, zdim, st);
+  return dispatch<256, 192>(d, p, zdim, st);
 }
 
 }  // namespace htrvt

@@ -12,7 +12,36 @@ import htrvt_amd  # noqa: E402
 from htrvt_amd import ops  # noqa: E402
 
 
+LIBS = None
+ROUNDS = 1
+
+
+TILES = []
+TILE = 0
+
+
 def timeit(fn, iters):
+    global TILE
+    if TILES:
+        best = {}
+        for _ in range(ROUNDS):
+            for t in TILES:
+                TILE = t
+                best[f"tile{t}"] = min(best.get(f"tile{t}", 1e9), _timeit(fn, iters))
+        TILE = 0
+        return best
+    if LIBS is not None and len(LIBS) > 1:      # interleaved A/B rounds, report min per lib
+        best = {}
+        for _ in range(ROUNDS):
+            for name, l in LIBS.items():
+                ops.lib = l
+                t = _timeit(fn, iters)
+                best[name] = min(best.get(name, 1e9), t)
+        return best
+    return _timeit(fn, iters)
+
+
+def _timeit(fn, iters):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -29,7 +58,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--libs", nargs="*", default=[], help="A/B: alternative builds of libhtrvt_hip.so, timed interleaved in this process")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--tiles", nargs="*", type=int, default=[], help="A/B over the `tile` selector of htrvt_gemm (2: DMA BM=128, 3: DMA BM=256)")
     args = ap.parse_args()
+    libs = {"default": ops.lib}
+    for path in args.libs:
+        import ctypes
+        from htrvt_amd import _lib
+        l = ctypes.CDLL(os.path.abspath(path))
+        for name, (res, argt) in _lib.PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, argt
+        libs[os.path.basename(path)] = l
+    if args.libs:
+        libs.pop("default")
+    global LIBS, ROUNDS, TILES
+    LIBS, ROUNDS, TILES = libs, args.rounds, args.tiles
+    _gemm = ops.gemm
+
+    def gemm_t(*a, **kw):
+        kw.setdefault("tile", TILE)
+        return _gemm(*a, **kw)
+    ops.gemm = gemm_t
     dt = torch.bfloat16
     dev = "cuda"
     rnd = lambda *s: (torch.rand(*s, device=dev) - 0.5).to(dt)  # noqa: E731
@@ -91,7 +142,10 @@ def main():
         conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
         conv("l2.0 192->384 s2 [128,8,1024]", 128, 8, 1024, 192, 384, 3, (2, 2), 1)
     for tag, ms, fl in rows:
-        print(f"{tag:42s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if isinstance(ms, dict):
+            print(f"{tag:42s} " + "  ".join(f"{k}: {v:7.3f} ms {fl / v / 1e9:7.1f} TF" for k, v in ms.items()))
+        else:
+            print(f"{tag:42s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

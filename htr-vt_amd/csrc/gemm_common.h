@@ -56,8 +56,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // NWM = number of waves stacked along M in the workgroup (for the BN column-sum reduction through LDS).
 template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS>
 __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KParams& p, char* Cb, long long coff, int mrow0,
-                                              int ncol0, int wm, int n0, int tile_m, int lane, char* smem) {
+                                              int ncol0, int wm, int n0, int tile_m, int lane, char* smem,
+                                              bool active = true) {
+  // active == false: a wave that holds no accumulators (dedicated loader wave); it only joins the barriers
   const int h = lane >> 5, cl = lane & 31;
+  if (!active) mrow0 = 0x3fffff00;  // every row test below fails
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
@@ -111,7 +114,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
     for (int j = 0; j < TN; ++j) {
       const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
       const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (h == 0) {
+      if (h == 0 && active) {
         const int c = ncol0 - n0 + j * 32 + cl;
         red[(wm * BN + c) * 2 + 0] = s1;
         red[(wm * BN + c) * 2 + 1] = s2;

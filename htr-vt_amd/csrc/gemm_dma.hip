@@ -249,16 +249,17 @@ struct Stg {
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <int TN, int BN, int BM>
+template <int TN, int BN, int BM, int NW_TOTAL>
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
-                                                int wm, int wn, int tile_m, int lane, int wave, char* smem) {
+                                                int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
-  constexpr int NWAVES = BM / 32, NTH = BM * 2, NWM = BM / 64;
+  constexpr int NWAVES = NW_TOTAL, NTH = NW_TOTAL * 64, NWM = BM / 64;
   const int h = lane >> 5, cl = lane & 31;
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
-  // ---- phase 1: registers -> LDS (column-major bf16) ----
+  // ---- phase 1: registers -> LDS (column-major bf16); loader waves hold no accumulators ----
+  if (active) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int ccol = (wn * TN + j) * 32 + cl;
@@ -283,6 +284,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
         *reinterpret_cast<uint2*>(smem + ccol * CST + crow * 2) = o;
       }
     }
+  }
   }
   __syncthreads();
   // ---- phase 2: LDS -> (act / residual) -> global, 16 B per lane, 4 lanes = 64 contiguous bytes of one row ----
@@ -348,7 +350,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
     for (int j = 0; j < TN; ++j) {
       const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
       const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (h == 0) {
+      if (h == 0 && active) {
         const int c = (wn * TN + j) * 32 + cl;
         red[(wm * BN + c) * 2 + 0] = s1;
         red[(wm * BN + c) * 2 + 1] = s2;
@@ -372,10 +374,16 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   }
 }
 
-template <int BM, int BN, int AL, int BL, int GATHER>
-__global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
+// SPEC = 0: every wave issues its share of the DMA, then multiplies (NTH = 2*BM).
+// SPEC = 1: wave specialisation -- 4 extra loader waves own ALL address arithmetic + DMA issue of the next k-tile
+//           while the BM/32 consumer waves run nothing but ds_read + MFMA; one workgroup barrier per k-tile.
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
+__global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KParams p) {
   using T = bf16_t;
-  constexpr int NTH = BM * 2, NWAVES = BM / 32;
+  constexpr int NWC = BM / 32;                 // consumer (MFMA) waves
+  constexpr int NWL = SPEC ? 4 : NWC;          // waves that issue DMA
+  constexpr int NW_TOTAL = NWC + (SPEC ? 4 : 0);
+  constexpr int NTH = NW_TOTAL * 64;
   constexpr int TM = 2, TN = BN / 64;
   constexpr int A_BYTES = Geo<BM>::BYTES, B_BYTES = Geo<BN>::BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -404,12 +412,15 @@ __global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const bool consumer = wave < NWC;
+  const bool loader = SPEC ? !consumer : true;
+  const int lw = SPEC ? (wave - NWC) & 3 : wave;   // index among the DMA-issuing waves
+  const int wm = (wave >> 1) % (BM / 64), wn = wave & 1;
 
-  DmaLoader<BM, AL, GATHER, NWAVES> la;
-  DmaLoader<BN, BL, 0, NWAVES> lb;
-  la.init(p, Ab, p.lda, m0, p.M, wave, lane);
-  lb.init(p, Bb, p.ldb, n0, p.N, wave, lane);
+  DmaLoader<BM, AL, GATHER, NWL> la;
+  DmaLoader<BN, BL, 0, NWL> lb;
+  la.init(p, Ab, p.lda, m0, p.M, lw, lane);  // unconditional: the descriptors must stay provably wave-uniform (SGPRs)
+  lb.init(p, Bb, p.ldb, n0, p.N, lw, lane);
 
   f32x16_t acc[TM][TN];
 #pragma unroll
@@ -422,9 +433,9 @@ __global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const unsigned lds0 = lds_addr_of(smem);
   constexpr bool KMAP = (GATHER == 1 || GATHER == 2);
-  if (nkt > 0) {
-    la.issue(p, lds0, kbeg, kend, wave);
-    lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, wave);
+  if (nkt > 0 && loader) {
+    la.issue(p, lds0, kbeg, kend, lw);
+    lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, lw);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -432,24 +443,26 @@ __global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
   for (int kt = 0; kt < nkt; ++kt) {
     char* cur = smem + (kt & 1) * STAGE;
     const unsigned nxt = lds0 + ((kt + 1) & 1) * STAGE;
-    if (kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
-      la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, wave);
-      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, wave);
+    if (loader && kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
+      la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, lw);
+      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, lw);
     }
-    const char* sa = cur;
-    const char* sb = cur + A_BYTES;
+    if (consumer) {
+      const char* sa = cur;
+      const char* sb = cur + A_BYTES;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8_t fa[TM], fb[TN];
+      for (int s = 0; s < 4; ++s) {
+        bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
+        for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
+        for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -457,17 +470,18 @@ __global__ __launch_bounds__(BM * 2) void gemm_dma_kernel(const KParams p) {
 
   // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
   if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN, BM>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem);
+    epilogue_staged<TN, BN, BM, NW_TOTAL>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
   else
-    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
+    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
+                                               smem, consumer);
 }
 
-template <int BM, int BN, int AL, int BL, int GATHER>
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
 int launch(const KParams& p, int zdim, hipStream_t st) {
-  constexpr int NTH = BM * 2;
+  constexpr int NTH = BM * 2 + SPEC * 256;
   constexpr int smem = 2 * (Geo<BM>::BYTES + Geo<BN>::BYTES);
   static bool attr_done = false;
-  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER>;
+  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER, SPEC>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -481,22 +495,29 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
   return rc ? rc : 1;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int SPEC>
 int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st) {
   const int al = d->a_layout, bl = d->b_layout, g = d->gather;
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0, SPEC>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1, SPEC>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2, SPEC>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0, SPEC>(p, zdim, st);
+  if constexpr (SPEC == 0) {  // weight-gradient (MN-major A) shapes: loader waves lose there (measured), not built
+    if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, 0>(p, zdim, st);
+    if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, 0>(p, zdim, st);
+  }
   return 0;
 }
 
-int pick_bm(const HtrvtGemmDesc* d) {
-  if (d->tile == 2) return 128;
-  if (d->tile == 3) return 256;
-  return 256;
+constexpr int BM_ = 256;
+
+// tile selector: 0 auto, 3: every wave loads, 4: 4 dedicated loader waves.  Measured (tools/bench_gemm.py --tiles 3 4):
+// loader waves win 5-15 % on the conv forward/dgrad gathers and on K >= 2048 plain GEMMs, lose on MN-major A.
+bool use_loader_waves(const HtrvtGemmDesc* d) {
+  if (d->a_layout != HTRVT_KMAJOR) return false;
+  if (d->tile == 3) return false;
+  if (d->tile == 4) return true;
+  return d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_DGRAD || d->K >= 2048;
 }
 
 int pick_bn(int N) {
@@ -535,14 +556,13 @@ namespace htrvt {
 
 int gemm_dma_num_mtiles(const HtrvtGemmDesc* d) {
   if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1) return -1;
-  const int bm = pick_bm(d);
-  return (d->M + bm - 1) / bm;
+  return (d->M + BM_ - 1) / BM_;
 }
 
 int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
   if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1 || !extents_ok(d)) return 0;
-  const int bn = pick_bn(d->N), bm = pick_bm(d);
-  p.tiles_m = (d->M + bm - 1) / bm;
+  const int bn = pick_bn(d->N);
+  p.tiles_m = (d->M + BM_ - 1) / BM_;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;
   if (d->gather == HTRVT_GATHER_CONV_WGRAD) {
@@ -552,14 +572,14 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.howo_shift = b;
     }
   }
-  if (bm == 128) {
-    if (bn == 64) return dispatch<128, 64>(d, p, zdim, st);
-    if (bn == 128) return dispatch<128, 128>(d, p, zdim, st);
-    return dispatch<128, 192>(d, p, zdim, st);
+  if (use_loader_waves(d)) {
+    if (bn == 64) return dispatch<256, 64, 1>(d, p, zdim, st);
+    if (bn == 128) return dispatch<256, 128, 1>(d, p, zdim, st);
+    return dispatch<256, 192, 1>(d, p, zdim, st);
   }
-  if (bn == 64) return dispatch<256, 64>(d, p, zdim, st);
-  if (bn == 128) return dispatch<256, 128>(d, p, zdim, st);
-  return dispatch<256, 192>(d, p, zdim, st);
+  if (bn == 64) return dispatch<256, 64, 0>(d, p, zdim, st);
+  if (bn == 128) return dispatch<256, 128, 0>(d, p, zdim, st);
+  return dispatch<256, 192, 0>(d, p, zdim, st);
 }
 
 }  // namespace htrvt

@@ -300,59 +300,95 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------ first max-pool backward (index based) + ReLU mask
 // g[b,hi,wi,c] = (x*scale+shift > 0) * sum_{windows (ho,wo) containing (hi,wi) with idx == position} dpool[b,ho,wo,c]
+// One thread per (image, column, channel vector) marches down the input rows; a pooled row (gradient + arg-max
+// bytes of the three windows around this column) is loaded once and serves the three input rows it covers.
 template <typename T>
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dpool, const unsigned char* __restrict__ idx,
                                                          const T* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, T* __restrict__ g, int B, int H,
                                                          int W, int C) {
   constexpr int CH = Vec16<T>::N;
+  using Raw = decltype(Vec16<T>().raw);
   const int cvec = C / CH, Ho = (H - 1) / 2 + 1;
-  const long long total = (long long)B * H * W * cvec;
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
-    const int cv = (int)(i % cvec);
-    long long pix = i / cvec;
-    const int wi = (int)(pix % W);
-    pix /= W;
-    const int hi = (int)(pix % H), b = (int)(pix / H);
-    float acc[CH];
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= B * W * cvec) return;
+  const int cv = i % cvec, t = i / cvec;
+  const int wi = t % W, b = t / W;
+  // window column wo = wi + 1 - dx  (dx = 0, 1, 2)
+  const bool okc[3] = {wi < W - 1, true, wi > 0};
+  const int woc[3] = {min(wi + 1, W - 1), wi, max(wi - 1, 0)};
+  float sc[CH], sf[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
-    // windows: 2*ho - 1 + dy == hi, dy in 0..2
+  for (int j = 0; j < CH; ++j) {
+    sc[j] = scale[cv * CH + j];
+    sf[j] = shift[cv * CH + j];
+  }
+  const Raw* db = reinterpret_cast<const Raw*>(dpool) + (long long)b * Ho * W * cvec + cv;
+  const unsigned char* ib = idx + ((long long)b * Ho * W * cvec + cv) * CH;
+  const Raw* xb = reinterpret_cast<const Raw*>(x) + ((long long)b * H * W + wi) * cvec + cv;
+  Raw* gb = reinterpret_cast<Raw*>(g) + ((long long)b * H * W + wi) * cvec + cv;
+
+  struct PRow {
+    Vec16<T> d[3];
+    unsigned w[3][2];
+  };
+  auto load_row = [&](int ho, PRow& r) {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int t = hi + 1 - dy;
-      if (t < 0 || (t & 1)) continue;
-      const int ho = t >> 1;
-      if (ho >= Ho) continue;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int wo = wi + 1 - dx;
-        if (wo < 0 || wo >= W) continue;
-        const long long o = (((long long)b * Ho + ho) * W + wo) * cvec + cv;
-        Vec16<T> vd;
-        vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dpool)[o];
-        const unsigned char* ip = idx + o * CH;
-        unsigned char id[CH];
-        if constexpr (CH == 8) {
-          const uint2 u = *reinterpret_cast<const uint2*>(ip);
-          *reinterpret_cast<uint2*>(id) = u;
-        } else {
-          const unsigned u = *reinterpret_cast<const unsigned*>(ip);
-          *reinterpret_cast<unsigned*>(id) = u;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-          if (id[j] == dy * 3 + dx) acc[j] += vd.get(j);
+    for (int dx = 0; dx < 3; ++dx) {
+      const long long o = (long long)(ho * W + woc[dx]) * cvec;
+      r.d[dx].raw = db[o];
+      if constexpr (CH == 8) {
+        const uint2 u = *reinterpret_cast<const uint2*>(ib + o * CH);
+        r.w[dx][0] = u.x;
+        r.w[dx][1] = u.y;
+      } else {
+        r.w[dx][0] = *reinterpret_cast<const unsigned*>(ib + o * CH);
+        r.w[dx][1] = 0;
       }
     }
-    Vec16<T> vx, o;
-    vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
+  };
+  // contribution of pooled row `r` to an input row that sits at window row `dy` of it
+  auto gather = [&](const PRow& r, unsigned dy, bool rowok, float(&acc)[CH]) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const float a = fmaf(vx.get(j), scale[cv * CH + j], shift[cv * CH + j]);
-      o.set(j, a > 0.f ? acc[j] : 0.f);
+    for (int dx = 0; dx < 3; ++dx) {
+      const unsigned pos = dy * 3 + dx;
+      const bool ok = rowok && okc[dx];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const unsigned idj = (r.w[dx][j >> 2] >> (8 * (j & 3))) & 0xffu;
+        acc[j] += (ok && idj == pos) ? r.d[dx].get(j) : 0.f;
+      }
     }
-    reinterpret_cast<decltype(o.raw)*>(g)[i] = o.raw;
+  };
+  auto finish = [&](int hi, const float(&acc)[CH]) {
+    Vec16<T> vx, o;
+    vx.raw = xb[(long long)hi * W * cvec];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o.set(j, fmaf(vx.get(j), sc[j], sf[j]) > 0.f ? acc[j] : 0.f);
+    gb[(long long)hi * W * cvec] = o.raw;
+  };
+
+  PRow cur, nxt;
+  load_row(0, cur);
+  for (int ho = 0; ho < Ho; ++ho) {
+    const bool has_next = ho + 1 < Ho;
+    load_row(has_next ? ho + 1 : ho, nxt);
+    {  // input row 2*ho: centre row (dy = 1) of pooled row ho
+      float acc[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+      gather(cur, 1u, true, acc);
+      finish(2 * ho, acc);
+    }
+    if (2 * ho + 1 < H) {  // input row 2*ho+1: top row (dy = 0) of pooled row ho+1, bottom row (dy = 2) of row ho
+      float acc[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+      gather(nxt, 0u, has_next, acc);
+      gather(cur, 2u, true, acc);
+      finish(2 * ho + 1, acc);
+    }
+    cur = nxt;
   }
 }
 
@@ -659,8 +695,8 @@ extern "C" int htrvt_maxpool_bwd(const void* dpool, const uint8_t* idx, const vo
                                  const float* shift, void* g, int B, int H, int W, int C, int dtype, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0, "htrvt_maxpool_bwd: C=%d unsupported", C);
-  const long long total = (long long)B * H * W * (C / ch);
-  dim3 grid(grid_for(total));
+  HTRVT_REQUIRE((long long)B * W * (C / ch) < (1ll << 31), "htrvt_maxpool_bwd: too many columns");
+  dim3 grid((unsigned)(((long long)B * W * (C / ch) + NT - 1) / NT));
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dpool, idx,
                                        (const T*)x, scale, shift, (T*)g, B, H, W, C));
   return check_launch("maxpool_bwd");

@@ -131,17 +131,26 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const float* __restrict__
   if (rl == 0 && c < C2) out[(long long)blockIdx.y * C2 + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, float count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                   float* save_mean, float* save_rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one block per 64 channels: 256 threads = 64 channels x 4 row lanes (coalesced partial rows), LDS combine
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, float count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float* running_mean, float* running_var,
+                                                         float* scale, float* shift, float* save_mean, float* save_rstd) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s1 += partial[(long long)r * 2 * C + c];
-    s2 += partial[(long long)r * 2 * C + C + c];
-  }
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) {
+      s1 += partial[(long long)r * 2 * C + c];
+      s2 += partial[(long long)r * 2 * C + C + c];
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -193,59 +202,98 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
 }
 
 // ------------------------------------------------------------------ BN + ReLU + maxpool 3x3 s(2,1) p1
+// One thread per (image, column, 16-byte channel vector) MARCHES down the rows: the horizontal first-maximum of
+// each input row is computed once (it serves the two vertically overlapping windows), BN + ReLU is applied once
+// per loaded element, and every step issues its 6 loads up front.  (A thread-per-output version spent ~1160
+// instructions per vector and was VALU-issue bound at 1.7 TB/s.)  First maximum in (row, column) scan order, as
+// ATen's max_pool2d; selects only, no branches.
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ y,
                                                              unsigned char* __restrict__ idx, int B, int H, int W,
                                                              int C) {
   constexpr int CH = Vec16<T>::N;
+  using Raw = decltype(Vec16<T>().raw);
   const int cvec = C / CH, Ho = (H - 1) / 2 + 1;
-  const long long total = (long long)B * Ho * W * cvec;
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
-    const int cv = (int)(i % cvec);
-    long long pix = i / cvec;
-    const int wo = (int)(pix % W);
-    pix /= W;
-    const int ho = (int)(pix % Ho), b = (int)(pix / Ho);
-    float sc[CH], sf[CH], m[CH];
-    unsigned char am[CH];
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= B * W * cvec) return;
+  const int cv = i % cvec, t = i / cvec;
+  const int wo = t % W, b = t / W;
+  const bool okL = wo > 0, okR = wo < W - 1;
+  const int wl = max(wo - 1, 0), wr = min(wo + 1, W - 1);
+  float sc[CH], sf[CH], pm[CH];
+  unsigned pi[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    sc[j] = scale ? scale[cv * CH + j] : 1.f;
+    sf[j] = scale ? shift[cv * CH + j] : 0.f;
+    pm[j] = -INFINITY;  // row -1 is padding
+    pi[j] = 0;
+  }
+  const Raw* xb = reinterpret_cast<const Raw*>(x) + (long long)b * H * W * cvec + cv;
+  Raw* yb = reinterpret_cast<Raw*>(y) + ((long long)b * Ho * W + wo) * cvec + cv;
+  unsigned char* ib = idx ? idx + (((long long)b * Ho * W + wo) * cvec + cv) * CH : nullptr;
+
+  auto row_max = [&](const Vec16<T>& l, const Vec16<T>& c, const Vec16<T>& r, bool rowok, float(&hm)[CH], unsigned(&hi)[CH]) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      sc[j] = scale ? scale[cv * CH + j] : 1.f;
-      sf[j] = scale ? shift[cv * CH + j] : 0.f;
-      m[j] = -INFINITY;
-      am[j] = 0;
-    }
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int hi = 2 * ho + dy;
-      if (hi < 0 || hi >= H) continue;
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int wi = wo + dx;
-        if (wi < 0 || wi >= W) continue;
-        Vec16<T> v;
-        v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[(((long long)b * H + hi) * W + wi) * cvec + cv];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          float a = fmaf(v.get(j), sc[j], sf[j]);
-          if (scale) a = fmaxf(a, 0.f);
-          if (a > m[j]) {  // first maximum in (row, column) scan order, as ATen's max_pool2d
-            m[j] = a;
-            am[j] = (unsigned char)((dy + 1) * 3 + (dx + 1));
-          }
-        }
+      float v0 = fmaf(l.get(j), sc[j], sf[j]), v1 = fmaf(c.get(j), sc[j], sf[j]), v2 = fmaf(r.get(j), sc[j], sf[j]);
+      if (scale) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        v2 = fmaxf(v2, 0.f);
       }
+      v0 = okL ? v0 : -INFINITY;
+      v2 = okR ? v2 : -INFINITY;
+      const bool t1 = v1 > v0;
+      const float m01 = t1 ? v1 : v0;
+      const bool t2 = v2 > m01;
+      hm[j] = rowok ? (t2 ? v2 : m01) : -INFINITY;
+      hi[j] = t2 ? 2u : (t1 ? 1u : 0u);
     }
+  };
+
+  for (int ho = 0; ho < Ho; ++ho) {
+    const int r1 = 2 * ho, r2 = min(2 * ho + 1, H - 1);
+    const bool ok2 = 2 * ho + 1 < H;
+    Vec16<T> a0, a1, a2, b0, b1, b2;
+    a0.raw = xb[(long long)(r1 * W + wl) * cvec];
+    a1.raw = xb[(long long)(r1 * W + wo) * cvec];
+    a2.raw = xb[(long long)(r1 * W + wr) * cvec];
+    b0.raw = xb[(long long)(r2 * W + wl) * cvec];
+    b1.raw = xb[(long long)(r2 * W + wo) * cvec];
+    b2.raw = xb[(long long)(r2 * W + wr) * cvec];
+    float m1[CH], m2[CH];
+    unsigned i1[CH], i2[CH];
+    row_max(a0, a1, a2, true, m1, i1);
+    row_max(b0, b1, b2, ok2, m2, i2);
     Vec16<T> o;
+    unsigned am[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) o.set(j, m[j]);
-    reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
-    if (idx != nullptr) {
-      if constexpr (CH == 8)
-        *reinterpret_cast<uint2*>(idx + i * CH) = *reinterpret_cast<const uint2*>(am);
-      else
-        *reinterpret_cast<unsigned*>(idx + i * CH) = *reinterpret_cast<const unsigned*>(am);
+    for (int j = 0; j < CH; ++j) {
+      float m = pm[j];
+      unsigned a = pi[j];
+      const bool t1 = m1[j] > m;
+      m = t1 ? m1[j] : m;
+      a = t1 ? 3u + i1[j] : a;
+      const bool t2 = m2[j] > m;
+      m = t2 ? m2[j] : m;
+      a = t2 ? 6u + i2[j] : a;
+      o.set(j, m);
+      am[j] = a;
+      pm[j] = m2[j];  // input row 2*ho+1 is the top row of the next window
+      pi[j] = i2[j];
+    }
+    yb[(long long)ho * W * cvec] = o.raw;
+    if (ib != nullptr) {
+      const unsigned w0 = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+      unsigned char* dst = ib + (long long)ho * W * cvec * CH;
+      if constexpr (CH == 8) {
+        const unsigned w1 = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+      } else {
+        *reinterpret_cast<unsigned*>(dst) = w0;
+      }
     }
   }
 }
@@ -340,7 +388,7 @@ extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float co
     src = scratch;
     r = 64;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, r, C, count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(NT), 0, (hipStream_t)stream, src, r, C, count, gamma,
                      beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
   return check_launch("bn_finalize");
 }
@@ -380,8 +428,8 @@ extern "C" int htrvt_bn_relu_maxpool(const void* x, const float* scale, const fl
                                      int H, int W, int C, int dtype, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_relu_maxpool: C=%d must be a multiple of %d", C, ch);
-  const long long total = (long long)B * ((H - 1) / 2 + 1) * W * (C / ch);
-  dim3 grid(grid_for(total));
+  HTRVT_REQUIRE((long long)B * W * (C / ch) < (1ll << 31), "htrvt_bn_relu_maxpool: too many columns");
+  dim3 grid((unsigned)(((long long)B * W * (C / ch) + NT - 1) / NT));
   if (dtype == HTRVT_BF16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, scale,
                        shift, (bf16_t*)y, idx, B, H, W, C);

@@ -32,6 +32,8 @@ class GemmDesc(C.Structure):
         ("cls_h", i32), ("cls_w", i32),
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
         ("bias", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
+        ("relu_src", vp), ("bnb_x", vp * 2), ("bnb_mean", vp * 2), ("bnb_rstd", vp * 2), ("bnb_partial", vp * 2),
+        ("bnb_tile0", i32),
         ("A", vp), ("B", vp), ("C", vp),
     ]
 

@@ -443,6 +443,15 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;
+  p.relu_src = (const char*)d->relu_src;
+  for (int t = 0; t < 2; ++t) {
+    p.bnb_x[t] = (const char*)d->bnb_x[t];
+    p.bnb_mean[t] = d->bnb_mean[t];
+    p.bnb_rstd[t] = d->bnb_rstd[t];
+    p.bnb_partial[t] = d->bnb_partial[t];
+  }
+  p.bnb_tile0 = d->bnb_tile0;
+  const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   p.cls_h = p.cls_w = -1;
   p.Hq = d->Hi; p.Wq = d->Wi;
   p.ntapsel = d->kh * d->kw;
@@ -469,6 +478,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
     if (r != 0) return r < 0 ? r : 0;
   }
   HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");
+  HTRVT_REQUIRE(!fused_bwd, "htrvt_gemm: relu_src / bnb_* need the bfloat16 LDS-DMA kernel with loader waves");
   if (d->dtype == HTRVT_BF16) {
     if (bn == 64) return dispatch_layout<bf16_t, 128, 64>(d, p, zdim, st);
     if (bn == 128) return dispatch_layout<bf16_t, 128, 128>(d, p, zdim, st);

@@ -44,6 +44,13 @@ struct KParams {
   // K runs over the class's valid taps only (tapsel); cls_h < 0: all pixels, all taps
   int cls_h, cls_w, Hq, Wq, ntapsel;
   unsigned char tapsel[12];
+  // fused backward-of-ReLU and BatchNorm-backward column sums in the bf16 staged epilogue (conv dgrad outputs)
+  const char* relu_src;
+  const char* bnb_x[2];
+  const float* bnb_mean[2];
+  const float* bnb_rstd[2];
+  float* bnb_partial[2];
+  int bnb_tile0;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

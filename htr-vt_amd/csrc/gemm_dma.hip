@@ -51,7 +51,15 @@ struct Geo {
   static constexpr int BYTES = ROWS * 128;      // both layouts: ROWS * 64 k * 2 B
   static constexpr int NP = ROWS / 8 / NWAVES;  // 1-KiB DMA pieces per wave per k-tile
   static constexpr int CPR_MN = ROWS / 8;       // 16-byte chunks per k-row of an MN-major tile
-  static constexpr int ROT = (ROWS >= 128) ? 4 : 0;
+  // rotation (in 16-byte chunks) of k-row k of an MN-major tile, chosen so that the four k-rows one
+  // ds_read_b64_tr_b16 half-wave touches land on four different 64-byte bank groups:
+  //   256- / 512-byte rows start on a bank-line boundary      -> 4 * (k & 3)
+  //   384-byte rows start at 0 / 128 alternately (k & 1)       -> 4 * ((k >> 1) & 1)   (exhaustive search)
+  static __device__ __forceinline__ int rot(int k) {
+    if constexpr (ROWS == 192) return 4 * ((k >> 1) & 1);
+    else if constexpr (ROWS >= 128) return 4 * (k & 3);
+    else return 0;
+  }
 };
 
 __device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int& ho, int& wo) {
@@ -127,7 +135,7 @@ struct DmaLoader {
       } else {
         const int s = pi * 64 + lane;
         const int krow = s / G::CPR_MN, cl = s - krow * G::CPR_MN;
-        int cg = cl - G::ROT * (krow & 3);
+        int cg = cl - G::rot(krow);
         if (cg < 0) cg += G::CPR_MN;
         const int col = row0 + cg * 8;
         c2[i] = krow;
@@ -199,6 +207,14 @@ struct DmaLoader {
         v = v && (k < kend);
         if constexpr (ROLE == 0) {
           off += (unsigned)k * ld2;
+        } else if (p.wo_shift >= 6) {
+          // Wo is a power of two >= 64 and k0 is a multiple of 64: the whole k-tile lies in ONE output row, so
+          // (b, ho, wo0) are scalars and only the column varies per lane
+          const int bq = k0 >> p.howo_shift, rq = k0 & ((1 << p.howo_shift) - 1);
+          const int hoq = rq >> p.wo_shift, wo0 = rq & ((1 << p.wo_shift) - 1);
+          const int hi = hoq * p.sh + c0[i], wi = (wo0 + c2[i]) * p.sw + c1[i];
+          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+          off += (unsigned)(((bq * p.Hi + hi) * p.Wi + wi) * p.Ci) * 2;
         } else {
           int b, ho, wo;
           pix_decode(p, k, b, ho, wo);
@@ -223,7 +239,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, in
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
-    int chunk = rb * 4 + 2 * (g & 1) + (pp >> 1) + G::ROT * q;
+    int chunk = rb * 4 + 2 * (g & 1) + (pp >> 1) + G::rot(q);
     if (chunk >= G::CPR_MN) chunk -= G::CPR_MN;
     const int krow = 16 * s + 8 * h + q;
     const char* a0 = lds + krow * (ROWS * 2) + chunk * 16 + (pp & 1) * 8;
@@ -249,7 +265,8 @@ struct Stg {
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <int TN, int BN, int BM, int NW_TOTAL>
+// DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
+template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD>
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
@@ -293,55 +310,138 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   const int lr = lane & 15, lg = lane >> 4;
   const int q = lr >> 2, pp = lr & 3;
   typedef __attribute__((address_space(3))) s16x4_t* lptr;
-  for (int id = wave; id < ITEMS; id += NWAVES) {
-    const int rbk = id / GROUPS, cg = id - rbk * GROUPS;
-    const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
-    const char* a0 = smem + (ccol0 + q) * CST + (crow0 + 4 * pp) * 2;
-    const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
-    const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
-    int m = m0 + crow0 + lr;
-    const int n = n0 + ccol0;
-    if (m < p.M && n < p.N) {
+  // When the wave count is a multiple of the column groups every wave keeps ONE column group and walks the row
+  // blocks: a lane then owns 8 fixed columns, which lets it accumulate per-column BatchNorm-backward sums.
+  constexpr bool FIXED_COLS = (NWAVES % GROUPS) == 0;
+  constexpr int RB_STEP = FIXED_COLS ? NWAVES / GROUPS : 1;
+  const bool bnb = DGRAD && FIXED_COLS && p.bnb_partial[0] != nullptr;
+  const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
+  float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = bmu[t][e] = brs[t][e] = 0.f;
+  if (bnb) {
+    const int nc = n0 + (wave % GROUPS) * 32 + lg * 8;
+    if (nc < p.N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bmu[0][e] = p.bnb_mean[0][nc + e];
+        brs[0][e] = p.bnb_rstd[0][nc + e];
+        if (bnb2) {
+          bmu[1][e] = p.bnb_mean[1][nc + e];
+          brs[1][e] = p.bnb_rstd[1][nc + e];
+        }
+      }
+    }
+  }
+  // Items are processed U at a time: all global loads of the U items (residual, ReLU source, BN inputs, saved
+  // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
+  // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
+  constexpr int U = DGRAD ? 2 : 4;
+  const bool has_res = p.residual != nullptr, has_relu = DGRAD && p.relu_src != nullptr, has_pre_in = !DGRAD && p.act == 2;
+  for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
+    long long o[U];
+    bool ok[U];
+    uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = id0 + u * NWAVES;
+      int rbk, cg;
+      if constexpr (FIXED_COLS) {
+        cg = wave % GROUPS;
+        rbk = (wave / GROUPS) + ((id - wave) / NWAVES) * RB_STEP;
+      } else {
+        rbk = id / GROUPS;
+        cg = id - rbk * GROUPS;
+      }
+      const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
+      int m = m0 + crow0 + lr;
+      const int n = n0 + ccol0;
+      ok[u] = id < ITEMS && m < p.M && n < p.N;
       if (p.cls_h >= 0) {  // class row -> input-pixel row of the NHWC gradient
         const int hw = p.Hq * p.Wq;
         const int b = m / hw, r = m - b * hw;
         const int hq = r / p.Wq, wq = r - hq * p.Wq;
         m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
       }
-      const uint4 raw = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
-      float v[8] = {bf16lo(raw.x), bf16hi(raw.x), bf16lo(raw.y), bf16hi(raw.y),
-                    bf16lo(raw.z), bf16hi(raw.z), bf16lo(raw.w), bf16hi(raw.w)};
-      const long long o = coff + (long long)m * p.ldc + n;
+      o[u] = ok[u] ? coff + (long long)m * p.ldc + n : coff;   // coff itself is a valid element of every operand
+      if (has_res) rres[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + o[u]);
+      if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.relu_src) + o[u]);
+      if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.preact) + o[u]);
+      if (bnb) rbx[0][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + o[u]);
+      if (bnb2) rbx[1][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + o[u]);
+      const int idc = id < ITEMS ? id : wave;  // clamp the LDS address of a tail item
+      int rbk2, cg2;
+      if constexpr (FIXED_COLS) {
+        cg2 = cg;
+        rbk2 = (wave / GROUPS) + ((idc - wave) / NWAVES) * RB_STEP;
+      } else {
+        rbk2 = idc / GROUPS;
+        cg2 = idc - rbk2 * GROUPS;
+      }
+      const char* a0 = smem + (cg2 * 32 + lg * 8 + q) * CST + (rbk2 * 16 + 4 * pp) * 2;
+      const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+      const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
+      raw[u] = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[8] = {bf16lo(raw[u].x), bf16hi(raw[u].x), bf16lo(raw[u].y), bf16hi(raw[u].y),
+                    bf16lo(raw[u].z), bf16hi(raw[u].z), bf16lo(raw[u].w), bf16hi(raw[u].w)};
       bool touched = false;
-      if (p.act == 2) {
-        const uint4 pr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.preact) + o);
+      if (has_pre_in) {
+        const uint4 pr = rpre[u];
         const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
                             bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
         touched = true;
       } else if (p.preact != nullptr) {
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.preact) + o) = raw;
+        if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.preact) + o[u]) = raw[u];
       }
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
         touched = true;
       }
-      if (p.residual != nullptr) {
-        const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + o);
+      if (has_res) {
+        const uint4 rr = rres[u];
         v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
         v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
         touched = true;
       }
-      uint4 out = raw;
+      if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
+        const uint4 rs = rrelu[u];
+        const float y[8] = {bf16lo(rs.x), bf16hi(rs.x), bf16lo(rs.y), bf16hi(rs.y),
+                            bf16lo(rs.z), bf16hi(rs.z), bf16lo(rs.w), bf16hi(rs.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+        touched = true;
+      }
+      if (bnb) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !bnb2) break;
+          const uint4 xr = rbx[t][u];
+          const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
+                              bf16lo(xr.z), bf16hi(xr.z), bf16lo(xr.w), bf16hi(xr.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gv = ok[u] ? v[e] : 0.f;
+            bs1[t][e] += gv;
+            bs2[t][e] += gv * ((x[e] - bmu[t][e]) * brs[t][e]);
+          }
+        }
+      }
+      uint4 out = raw[u];
       if (touched) {
         out.x = pack_bf16x2(v[0], v[1]);
         out.y = pack_bf16x2(v[2], v[3]);
         out.z = pack_bf16x2(v[4], v[5]);
         out.w = pack_bf16x2(v[6], v[7]);
       }
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o) = out;
+      if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o[u]) = out;
     }
   }
   if (p.colstats != nullptr) {
@@ -369,6 +469,50 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
         }
         dst[n] = a;
         dst[p.N + n] = q2;
+      }
+    }
+  }
+  if constexpr (FIXED_COLS) {
+    if (bnb) {  // workgroup-uniform
+      float* red2 = reinterpret_cast<float*>(smem + BN * CST + NWM * BN * 8);  // [2 sets][RB_STEP][BN][2]
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int sft = 1; sft < 16; sft <<= 1) {
+            bs1[t][e] += __shfl_xor(bs1[t][e], sft, 64);
+            bs2[t][e] += __shfl_xor(bs2[t][e], sft, 64);
+          }
+        }
+      if (lr == 0) {
+        const int c0 = (wave % GROUPS) * 32 + lg * 8, slab = wave / GROUPS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            red2[((t * RB_STEP + slab) * BN + c0 + e) * 2 + 0] = bs1[t][e];
+            red2[((t * RB_STEP + slab) * BN + c0 + e) * 2 + 1] = bs2[t][e];
+          }
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < BN; c += NTH) {
+        const int n = n0 + c;
+        if (n < p.N) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !bnb2) break;
+            float a = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < RB_STEP; ++sl) {
+              a += red2[((t * RB_STEP + sl) * BN + c) * 2];
+              q2 += red2[((t * RB_STEP + sl) * BN + c) * 2 + 1];
+            }
+            float* dst = p.bnb_partial[t] + (long long)(p.bnb_tile0 + tile_m) * 2 * p.N;
+            dst[n] = a;
+            dst[p.N + n] = q2;
+          }
+        }
       }
     }
   }
@@ -470,7 +614,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
 
   // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
   if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN, BM, NW_TOTAL>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
+    epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
   else
     gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
                                                smem, consumer);
@@ -502,10 +646,8 @@ int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st)
   if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1, SPEC>(p, zdim, st);
   if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2, SPEC>(p, zdim, st);
   if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0, SPEC>(p, zdim, st);
-  if constexpr (SPEC == 0) {  // weight-gradient (MN-major A) shapes: loader waves lose there (measured), not built
-    if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, 0>(p, zdim, st);
-    if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, 0>(p, zdim, st);
-  }
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, SPEC>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, SPEC>(p, zdim, st);
   return 0;
 }
 
@@ -514,9 +656,9 @@ constexpr int BM_ = 256;
 // tile selector: 0 auto, 3: every wave loads, 4: 4 dedicated loader waves.  Measured (tools/bench_gemm.py --tiles 3 4):
 // loader waves win 5-15 % on the conv forward/dgrad gathers and on K >= 2048 plain GEMMs, lose on MN-major A.
 bool use_loader_waves(const HtrvtGemmDesc* d) {
-  if (d->a_layout != HTRVT_KMAJOR) return false;
   if (d->tile == 3) return false;
   if (d->tile == 4) return true;
+  if (d->a_layout != HTRVT_KMAJOR) return false;
   return d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_DGRAD || d->K >= 2048;
 }
 
@@ -561,6 +703,10 @@ int gemm_dma_num_mtiles(const HtrvtGemmDesc* d) {
 
 int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
   if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1 || !extents_ok(d)) return 0;
+  if (d->relu_src != nullptr || d->bnb_partial[0] != nullptr) {
+    // served only by the staged epilogue with a fixed column group per wave (12 waves, 6/4/2 column groups)
+    if (!use_loader_waves(d) || d->c_f32 || (d->ldc & 7) || (d->N & 7)) return 0;
+  }
   const int bn = pick_bn(d->N);
   p.tiles_m = (d->M + BM_ - 1) / BM_;
   p.tiles_n = (d->N + bn - 1) / bn;

@@ -70,6 +70,7 @@ class Engine:
         self.dti = dt(dtype)
         self._packs = {}      # name -> (version key, tensors)
         self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
+        self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.saved = None
 
     # ------------------------------------------------------------------ small helpers
@@ -186,21 +187,35 @@ class Engine:
              gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs)
         return y, cs, rows
 
-    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None):
+    def dgrad_tiles(self, g: ConvGeom):
+        """number of M tiles (rows of a fused BN-backward partial buffer) conv_dgrad will produce"""
+        if self._dgrad_by_class(g):
+            return sum(ops.gemm_num_mtiles(g.B * ((g.Hi - a + g.sh - 1) // g.sh) * ((g.Wi - b + g.sw - 1) // g.sw), g.Ci,
+                                           self.dtype, gather=GATHER_CONV_DGRAD) for a in range(g.sh) for b in range(g.sw))
+        return ops.gemm_num_mtiles(g.B * g.Hi * g.Wi, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
+
+    def _dgrad_by_class(self, g):
+        return self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
+
+    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None):
+        """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only)"""
         cpo = cpad(g.Co, self.dtype)
         dx = self._empty(g.B, g.Hi, g.Wi, g.Ci)
-        if self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128:
+        if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
+            tile0 = 0
             for a in range(g.sh):
                 for b in range(g.sw):
-                    nt = sum(1 for dy in range(g.kh) if (a + g.ph - dy) % g.sh == 0) * \
+                    nt = sum(1 for dy_ in range(g.kh) if (a + g.ph - dy_) % g.sh == 0) * \
                          sum(1 for dx_ in range(g.kw) if (b + g.pw - dx_) % g.sw == 0)
                     Hq, Wq = (g.Hi - a + g.sh - 1) // g.sh, (g.Wi - b + g.sw - 1) // g.sw
                     gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
-                         ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b))
+                         ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b),
+                         relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, tile=4 if (relu_src is not None or bnb) else 0)
+                    tile0 += ops.gemm_num_mtiles(g.B * Hq * Wq, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
             return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
-             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual)
+             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb)
         return dx
 
     def conv_wgrad(self, dy, x, g: ConvGeom, dw):
@@ -237,25 +252,33 @@ class Engine:
         return y
 
     def bn_backward(self, dy, yact, x, prefix, P, G, mean, rstd, want_g=False):
-        """dx of train-mode BN (+ReLU mask from yact); accumulates dgamma/dbeta into G."""
+        """dx of train-mode BN (+ReLU mask from yact); accumulates dgamma/dbeta into G.  Unfused form: one
+        reduction pass over (dy, yact, x), then bn_backward_finish."""
         C = x.shape[-1]
         npix = x.numel() // C
         nblk = lib.htrvt_bn_bwd_blocks(npix)
         partial = self._empty(nblk, 2, C, dtype=torch.float32)
         check(lib.htrvt_bn_bwd_reduce(ptr(dy), ptr(yact), ptr(x), ptr(mean), ptr(rstd), ptr(partial), npix, C, self.dti,
                                       stream()), "bn_bwd_reduce")
+        return self.bn_backward_finish(partial, nblk, dy, yact, x, prefix, P, G, mean, rstd, want_g)
+
+    def bn_backward_finish(self, partial, rows, g, yact, x, prefix, P, G, mean, rstd, want_g=False):
+        """finalize (dgamma, dbeta, coefficients) from per-tile partial sums, then dx = cA*g + cB*x + cC.
+        With yact=None, g is the already ReLU-masked gradient (fused dgrad epilogue)."""
+        C = x.shape[-1]
+        npix = x.numel() // C
         coef = self._empty(3, C, dtype=torch.float32)
-        src, rows = partial, nblk
-        if nblk > 64:   # two-level reduction of the partial rows
+        src = partial
+        if rows > 64:   # two-level reduction of the partial rows
             red = self._zeros(2 * C)
-            check(lib.htrvt_colsum(ptr(partial), nblk, 2 * C, 2 * C, ptr(red), None, 1, 0, stream()), "colsum")
+            check(lib.htrvt_colsum(ptr(partial), rows, 2 * C, 2 * C, ptr(red), None, 1, 0, stream()), "colsum")
             src, rows = red, 1
         check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, float(npix), ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
                                         ptr(G[prefix + ".weight"]), ptr(G[prefix + ".bias"]), ptr(coef), stream()),
               "bn_bwd_finalize")
         dx = torch.empty_like(x)
         gout = torch.empty_like(x) if want_g else None
-        check(lib.htrvt_bn_bwd_apply(ptr(dy), ptr(yact), ptr(x), ptr(coef), ptr(dx), ptr(gout), npix, C, self.dti, stream()),
+        check(lib.htrvt_bn_bwd_apply(ptr(g), ptr(yact), ptr(x), ptr(coef), ptr(dx), ptr(gout), npix, C, self.dti, stream()),
               "bn_bwd_apply")
         return dx, gout
 
@@ -487,28 +510,77 @@ class Engine:
         check(lib.htrvt_pool_tokens_bwd(ptr(dx), ptr(sv["l3"]), ptr(keep), ptr(dfeat), B, Hc, N, D, self.dti, st),
               "pool_tokens_bwd")
 
-        # residual stages
+        # residual stages.  bf16: the ReLU mask of a block's output and the BatchNorm-backward sums of its bn2 (and
+        # downsample BN) are produced by the epilogue of the dgrad GEMM that creates that gradient; float32 (parity
+        # path) keeps the separate reduction pass.
+        blocks = sv["stem_blocks"]
+
+        def can_fuse(g):   # served by the LDS-DMA kernel (bf16, > 128 rows per launch)
+            return (self.fuse_bn_backward and self.dtype == torch.bfloat16 and
+                    g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128 and g.Ci % 8 == 0)
+
+        def bnb_of(blk, C):
+            """fused-sum request for the gradient flowing into `blk`'s output"""
+            req = [(blk["cb"], blk["bn_b"][2], blk["bn_b"][3])]
+            if blk["gd"] is not None:
+                req.append((blk["cd"], blk["bn_d"][2], blk["bn_d"][3]))
+            return req
+
+        # gradient into the last block's output comes from the token kernel: unfused reduce for that one
+        gm, parts = None, None
         dout = dfeat
-        for blk in reversed(sv["stem_blocks"]):
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk = blocks[bi]
             p = blk["p"]
-            # out = relu(bn2(cb) + res): g = dout * (out > 0)
-            dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3], want_g=True)
+            C = blk["cb"].shape[-1]
+            if parts is None:   # dout is an unmasked gradient: classic path (mask + sums in one reduction pass)
+                dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3],
+                                           want_g=True)
+                parts_d = None
+            else:               # dout is already g = dOut * (out > 0) and the sums exist
+                gm = dout
+                dcb, _ = self.bn_backward_finish(parts[0][0], parts[0][1], gm, None, blk["cb"], p + ".bn2", P, G,
+                                                 blk["bn_b"][2], blk["bn_b"][3])
+                parts_d = parts[1] if len(parts) > 1 else None
             _, wd2 = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
-            da1 = self.conv_dgrad(dcb, wd2, blk["g2"])
             self.conv_wgrad(dcb, blk["a1"], blk["g2"], G[p + ".conv2.weight"])
+            if can_fuse(blk["g2"]):
+                rows1 = self.dgrad_tiles(blk["g2"])
+                part1 = self._empty(rows1, 2, C, dtype=torch.float32)
+                g1 = self.conv_dgrad(dcb, wd2, blk["g2"], relu_src=blk["a1"],
+                                     bnb=[(blk["ca"], blk["bn_a"][2], blk["bn_a"][3], part1)])
+                dca, _ = self.bn_backward_finish(part1, rows1, g1, None, blk["ca"], p + ".bn1", P, G, blk["bn_a"][2],
+                                                 blk["bn_a"][3])
+                del g1
+            else:
+                da1 = self.conv_dgrad(dcb, wd2, blk["g2"])
+                dca, _ = self.bn_backward(da1, blk["a1"], blk["ca"], p + ".bn1", P, G, blk["bn_a"][2], blk["bn_a"][3])
+                del da1
             del dcb
-            dca, _ = self.bn_backward(da1, blk["a1"], blk["ca"], p + ".bn1", P, G, blk["bn_a"][2], blk["bn_a"][3])
-            del da1
             _, wd1 = self._conv_w(p + ".conv1", P[p + ".conv1.weight"])
             self.conv_wgrad(dca, blk["x"], blk["g1"], G[p + ".conv1.weight"])
+            # what the gradient of this block's INPUT feeds: the previous block's output (ReLU + bn2 [+ downsample BN])
+            prev = blocks[bi - 1] if bi > 0 else None
+            kw, parts = {}, None
+            if prev is not None and can_fuse(blk["g1"]):
+                Cp = prev["cb"].shape[-1]
+                rows = self.dgrad_tiles(blk["g1"])
+                req = bnb_of(prev, Cp)
+                bufs = [self._empty(rows, 2, Cp, dtype=torch.float32) for _ in req]
+                kw = dict(relu_src=prev["out"], bnb=[(x_, m_, r_, b_) for (x_, m_, r_), b_ in zip(req, bufs)])
+                parts = [(b_, rows) for b_ in bufs]
             if blk["gd"] is not None:
-                dcd, _ = self.bn_backward(gm, None, blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3])
+                if parts_d is not None:
+                    dcd, _ = self.bn_backward_finish(parts_d[0], parts_d[1], gm, None, blk["cd"], p + ".downsample.1", P, G,
+                                                     blk["bn_d"][2], blk["bn_d"][3])
+                else:
+                    dcd, _ = self.bn_backward(gm, None, blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3])
                 _, wdd = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
                 self.conv_wgrad(dcd, blk["x"], blk["gd"], G[p + ".downsample.0.weight"])
                 dres = self.conv_dgrad(dcd, wdd, blk["gd"])
-                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=dres)
+                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=dres, **kw)
             else:
-                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=gm)
+                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=gm, **kw)
 
         # first maxpool + bn1 + conv1
         img, c1 = sv["img"], sv["c1"]

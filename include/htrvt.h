@@ -71,6 +71,17 @@ typedef struct HtrvtGemmDesc {
   const void* residual;     /* same shape/type as C, added last, or NULL             */
   float* colstats;          /* [ceil(M/BM)][2][N]: per-M-tile column sum / sum of squares of the
                                float accumulators (before bias), or NULL           */
+  /* bfloat16 conv-dgrad outputs only (LDS-DMA kernel with loader waves, N tile 192/128/64):
+   * relu_src: same shape/type as C; C = (relu_src > 0) ? value : 0, applied after `residual` (backward of ReLU).
+   * bnb_*[t], t = 0,1: BatchNorm-backward sums of the (masked) gradient written to C against up to two raw conv
+   * outputs bnb_x[t] (same shape as C): bnb_partial[t][bnb_tile0 + m_tile][2][N] = { sum g, sum g*(x-mean)*rstd }.
+   * bnb_partial[0] == NULL disables it. */
+  const void* relu_src;
+  const void* bnb_x[2];
+  const float* bnb_mean[2];
+  const float* bnb_rstd[2];
+  float* bnb_partial[2];
+  int32_t bnb_tile0;
   const void* A;
   const void* B;
   void* C;

@@ -168,3 +168,32 @@ def test_create_model_surface_and_bf16_training_step():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all().item(), n
     assert int(m.patch_embed.bn1.num_batches_tracked) == 1
+
+
+def test_bf16_gradients_track_f32_and_fused_equals_unfused():
+    """bf16 backward: (1) the fused ReLU-mask / BatchNorm-backward dgrad epilogue must reproduce the separate
+    reduction pass (same math, different kernel) and (2) bf16 gradients must track the float32 parity path up to
+    bf16 noise (early-stem BN gradients are the noisiest: ~0.91 cosine at batch 8 in BOTH bf16 variants)."""
+    import htrvt_amd
+    cfg = O.Config(80, (64, 512), embed_dim=256, depth=2, num_heads=4)
+    sd = O.init_state_dict(cfg, seed=5, randomize_affine=True)
+    x, targets, lengths = O.synthetic_batch(8, 64, 512, 80, cfg.num_patches, seed=2)
+    torch.manual_seed(3)
+    keep = O.span_mask(cfg.num_patches, 0.4, 8)
+
+    def run(dtype, fuse):
+        m = _model(cfg, sd, dtype=dtype).train()
+        m._engine(torch.device("cuda", 0)).fuse_bn_backward = fuse
+        y = m(x.cuda(), keep_mask=keep)
+        htrvt_amd.ctc_loss(y, targets, lengths).backward()
+        return {n: p.grad.double().flatten() for n, p in m.named_parameters() if p.grad is not None}
+
+    def cos(a, b):
+        return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+    g32, gu, gf = run(torch.float32, False), run(torch.bfloat16, False), run(torch.bfloat16, True)
+    worst_fu = min(cos(gu[n], gf[n]) for n in g32)
+    worst_32 = min(cos(g32[n], gf[n]) for n in g32)
+    print("fused vs unfused bf16 worst cosine", worst_fu, "| bf16 vs f32 worst cosine", worst_32)
+    assert worst_fu > 0.995
+    assert worst_32 > 0.85

@@ -71,6 +71,8 @@ class Engine:
         self._packs = {}      # name -> (version key, tensors)
         self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
+        self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
+        self._side, self._side_active = None, False
         self.saved = None
 
     # ------------------------------------------------------------------ small helpers
@@ -166,7 +168,30 @@ class Engine:
                 best, best_t = s, t
         return best
 
+    # Weight gradients have no consumer inside backward: they run on a side stream, overlapping the
+    # (HBM-bound) BatchNorm / LayerNorm backward passes and the tails of the dgrad GEMMs on the main stream.
+    def _on_side(self, fn, *tensors):
+        if not self._side_active:
+            return fn()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(self._side)      # the caching allocator must not recycle them under the side stream
+        with torch.cuda.stream(self._side):
+            return fn()
+
+    def _join_side(self):
+        if self._side is not None and self._side_active:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def linear_wgrad(self, dy, x, dw, dbias):
+        return self._on_side(lambda: self._linear_wgrad(dy, x, dw, dbias), dy, x)
+
+    def conv_wgrad(self, dy, x, g, dw):
+        return self._on_side(lambda: self._conv_wgrad(dy, x, g, dw), dy, x)
+
+    def _linear_wgrad(self, dy, x, dw, dbias):
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
         M, N = dy.shape
         K = x.shape[1]
@@ -218,7 +243,7 @@ class Engine:
              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb)
         return dx
 
-    def conv_wgrad(self, dy, x, g: ConvGeom, dw):
+    def _conv_wgrad(self, dy, x, g: ConvGeom, dw):
         M = g.B * g.Ho * g.Wo
         cpi = cpad(g.Ci, self.dtype)
         packed = self._zeros(g.taps, cpi, g.Co)
@@ -440,6 +465,7 @@ class Engine:
         scale = hd ** -0.5
         dy = dy.contiguous()
         assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
+        self._side_active = self.overlap_wgrad
 
         # sequence LN, head, final norm
         Cp = (C + 7) // 8 * 8           # class dim padded so that every 16-byte chunk is aligned
@@ -453,6 +479,7 @@ class Engine:
         else:
             dwp, dbp = self._zeros(Cp, D), self._zeros(Cp)
             self.linear_wgrad(draw, sv["xn"], dwp, dbp)
+            self._join_side()
             check(lib.htrvt_rowsum_f32(ptr(dwp), 1, C * D, ptr(G["head.weight"]), st), "rowsum")
             check(lib.htrvt_rowsum_f32(ptr(dbp), 1, C, ptr(G["head.bias"]), st), "rowsum")
         dx = self.ln_bwd(dxn, sv["x_last"], sv["mn"], sv["rn"], P["norm.weight"], None, G["norm.weight"], G["norm.bias"])
@@ -499,6 +526,7 @@ class Engine:
                              G[p + ".norm1.bias"])
 
         if after_encoder is not None:   # every blocks.*, norm, head gradient is enqueued: DP bucket can go
+            self._join_side()
             after_encoder()
 
         # token assembly
@@ -595,4 +623,6 @@ class Engine:
         partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
         check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
                                     B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
+        self._join_side()
+        self._side_active = False
         self.saved = None

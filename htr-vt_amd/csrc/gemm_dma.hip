@@ -271,16 +271,53 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
   constexpr int NWAVES = NW_TOTAL, NTH = NW_TOTAL * 64, NWM = BM / 64;
+  // tiles wider than 192 columns are staged in two passes (the column-major staging image must fit the LDS)
+  constexpr int PASSES = BN > 192 ? 2 : 1;
+  constexpr int TNP = TN / PASSES, BNS = BN / PASSES;
   const int h = lane >> 5, cl = lane & 31;
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+  constexpr int GROUPS = BNS / 32;            // groups of 4 chunks (32 columns) per row
+  constexpr int ITEMS = (BM / 16) * GROUPS;   // wave-level items: 16 rows x 32 columns
+  const int lr = lane & 15, lg = lane >> 4;
+  const int q = lr >> 2, pp = lr & 3;
+  typedef __attribute__((address_space(3))) s16x4_t* lptr;
+  // When the wave count is a multiple of the column groups every wave keeps ONE column group and walks the row
+  // blocks: a lane then owns 8 fixed columns, which lets it accumulate per-column BatchNorm-backward sums.
+  constexpr bool FIXED_COLS = (NWAVES % GROUPS) == 0;
+  constexpr int RB_STEP = FIXED_COLS ? NWAVES / GROUPS : 1;
+  const bool bnb = DGRAD && FIXED_COLS && PASSES == 1 && p.bnb_partial[0] != nullptr;
+  const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
+  float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = bmu[t][e] = brs[t][e] = 0.f;
+  if (bnb) {
+    const int nc = n0 + (wave % GROUPS) * 32 + lg * 8;
+    if (nc < p.N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bmu[0][e] = p.bnb_mean[0][nc + e];
+        brs[0][e] = p.bnb_rstd[0][nc + e];
+        if (bnb2) {
+          bmu[1][e] = p.bnb_mean[1][nc + e];
+          brs[1][e] = p.bnb_rstd[1][nc + e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+  if (pass > 0) __syncthreads();   // the previous pass has drained the staging image
   // ---- phase 1: registers -> LDS (column-major bf16); loader waves hold no accumulators ----
   if (active) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int ccol = (wn * TN + j) * 32 + cl;
-    const int n = n0 + ccol;
+  for (int jp = 0; jp < TNP; ++jp) {
+    const int j = pass * TNP + jp;
+    const int ccol = (wn * TNP + jp) * 32 + cl;          // column in the staging image
+    const int n = n0 + (wn * TN + j) * 32 + cl;
     const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -305,36 +342,6 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   }
   __syncthreads();
   // ---- phase 2: LDS -> (act / residual) -> global, 16 B per lane, 4 lanes = 64 contiguous bytes of one row ----
-  constexpr int GROUPS = BN / 32;             // groups of 4 chunks (32 columns) per row
-  constexpr int ITEMS = (BM / 16) * GROUPS;   // wave-level items: 16 rows x 32 columns
-  const int lr = lane & 15, lg = lane >> 4;
-  const int q = lr >> 2, pp = lr & 3;
-  typedef __attribute__((address_space(3))) s16x4_t* lptr;
-  // When the wave count is a multiple of the column groups every wave keeps ONE column group and walks the row
-  // blocks: a lane then owns 8 fixed columns, which lets it accumulate per-column BatchNorm-backward sums.
-  constexpr bool FIXED_COLS = (NWAVES % GROUPS) == 0;
-  constexpr int RB_STEP = FIXED_COLS ? NWAVES / GROUPS : 1;
-  const bool bnb = DGRAD && FIXED_COLS && p.bnb_partial[0] != nullptr;
-  const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
-  float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = bmu[t][e] = brs[t][e] = 0.f;
-  if (bnb) {
-    const int nc = n0 + (wave % GROUPS) * 32 + lg * 8;
-    if (nc < p.N) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bmu[0][e] = p.bnb_mean[0][nc + e];
-        brs[0][e] = p.bnb_rstd[0][nc + e];
-        if (bnb2) {
-          bmu[1][e] = p.bnb_mean[1][nc + e];
-          brs[1][e] = p.bnb_rstd[1][nc + e];
-        }
-      }
-    }
-  }
   // Items are processed U at a time: all global loads of the U items (residual, ReLU source, BN inputs, saved
   // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
   // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
@@ -357,7 +364,8 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
       }
       const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
       int m = m0 + crow0 + lr;
-      const int n = n0 + ccol0;
+      const int half = ccol0 / (TNP * 32);                 // which wave column (wn) staged this column
+      const int n = n0 + (half * TN + pass * TNP) * 32 + (ccol0 - half * TNP * 32);
       ok[u] = id < ITEMS && m < p.M && n < p.N;
       if (p.cls_h >= 0) {  // class row -> input-pixel row of the NHWC gradient
         const int hw = p.Hq * p.Wq;
@@ -444,8 +452,9 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
       if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o[u]) = out;
     }
   }
+  }  // pass
   if (p.colstats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + BN * CST);  // [NWM][BN][2], behind the staged tile
+    float* red = reinterpret_cast<float*>(smem + BNS * CST);  // [NWM][BN][2], behind the staged tile
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
@@ -474,7 +483,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   }
   if constexpr (FIXED_COLS) {
     if (bnb) {  // workgroup-uniform
-      float* red2 = reinterpret_cast<float*>(smem + BN * CST + NWM * BN * 8);  // [2 sets][RB_STEP][BN][2]
+      float* red2 = reinterpret_cast<float*>(smem + BNS * CST + NWM * BN * 8);  // [2 sets][RB_STEP][BN][2]
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -662,7 +671,12 @@ bool use_loader_waves(const HtrvtGemmDesc* d) {
   return d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_DGRAD || d->K >= 2048;
 }
 
-int pick_bn(int N) {
+int pick_bn(const HtrvtGemmDesc* d) {
+  const int N = d->N;
+  const bool fused = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
+  // 256x256 tiles move 14 % fewer operand bytes per FLOP through the (per-CU, ~70 GB/s) LDS-DMA path than 256x192
+  // (256x384 would save 29 % but its 192 accumulator registers per wave do not fit beside the loader state)
+  if (N % 256 == 0 && !fused && (d->tile == 0 || d->tile == 6)) return 256;
   if (N <= 64) return 64;
   if (N <= 128) return 128;
   const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;
@@ -707,7 +721,7 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
     // served only by the staged epilogue with a fixed column group per wave (12 waves, 6/4/2 column groups)
     if (!use_loader_waves(d) || d->c_f32 || (d->ldc & 7) || (d->N & 7)) return 0;
   }
-  const int bn = pick_bn(d->N);
+  const int bn = pick_bn(d);
   p.tiles_m = (d->M + BM_ - 1) / BM_;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;
@@ -718,6 +732,7 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.howo_shift = b;
     }
   }
+  if (bn == 256) return dispatch<256, 256, 0>(d, p, zdim, st);
   if (use_loader_waves(d)) {
     if (bn == 64) return dispatch<256, 64, 1>(d, p, zdim, st);
     if (bn == 128) return dispatch<256, 128, 1>(d, p, zdim, st);

@@ -23,9 +23,11 @@ class FlatParams:
     """Flat float32 parameter / gradient storage + the two gradient buckets.  Device-agnostic (the
     world-size-2 gloo test drives it on CPU); on CUDA the encoder bucket is reduced on a side stream."""
 
-    def __init__(self, model, world_size=1):
+    def __init__(self, model, world_size=1, use_collectives=None):
         self.model = model
         self.world = world_size
+        # collectives run whenever a process group exists (also at world_size 1, which rehearses the RCCL path)
+        self.coll = (world_size > 1) if use_collectives is None else bool(use_collectives)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         dev = named[0][1].device
         total = sum((p.numel() + 3) // 4 * 4 for _, p in named)
@@ -43,8 +45,8 @@ class FlatParams:
             off += (k + 3) // 4 * 4
         if self.enc_start is None:
             self.enc_start = 0
-        self.side = torch.cuda.Stream(device=dev) if (world_size > 1 and dev.type == "cuda") else None
-        if world_size > 1:   # identical replicas: rank 0's parameters and BN buffers
+        self.side = torch.cuda.Stream(device=dev) if (self.coll and dev.type == "cuda") else None
+        if self.coll:   # identical replicas: rank 0's parameters and BN buffers
             dist.broadcast(self.flat_p, 0)
             for _, b in model.named_buffers():
                 dist.broadcast(b, 0)
@@ -58,7 +60,7 @@ class FlatParams:
     def reduce_encoder_bucket(self):
         """all-reduce(SUM) of the blocks.*/norm/head gradients; on CUDA on the side stream, overlapping
         whatever the current stream enqueues next (the stem backward)."""
-        if self.world == 1:
+        if not self.coll:
             return
         if self.side is None:
             dist.all_reduce(self.flat_g[self.enc_start:])
@@ -68,7 +70,7 @@ class FlatParams:
             dist.all_reduce(self.flat_g[self.enc_start:])
 
     def reduce_stem_bucket(self):
-        if self.world == 1:
+        if not self.coll:
             return
         dist.all_reduce(self.flat_g[:self.enc_start])
         if self.side is not None:
@@ -76,7 +78,8 @@ class FlatParams:
 
 
 class Trainer:
-    def __init__(self, model, max_lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.5, world_size=1):
+    def __init__(self, model, max_lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.5, world_size=1,
+                 use_collectives=None):
         from ._lib import lib  # noqa: F401  (fails loudly without the HIP library)
         self.model = model
         self.world = world_size
@@ -84,7 +87,7 @@ class Trainer:
         self.step_count = 0
         dev = next(model.parameters()).device
         assert dev.type == "cuda", "Trainer needs the model on an MI355X (model.cuda())"
-        self.flat = FlatParams(model, world_size)
+        self.flat = FlatParams(model, world_size, use_collectives)
         self.flat_m = torch.zeros_like(self.flat.flat_p)
         self.flat_v = torch.zeros_like(self.flat.flat_p)
         self.P = dict(model.state_dict(keep_vars=True))

@@ -46,11 +46,20 @@ __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
 
-template <int ROWS, int NWAVES = 8>
+template <int ROWS, int NWAVES = 8, int KB = 64>   // KB = k-tile depth in elements (64, or 32 for the deep pipeline)
 struct Geo {
-  static constexpr int BYTES = ROWS * 128;      // both layouts: ROWS * 64 k * 2 B
-  static constexpr int NP = ROWS / 8 / NWAVES;  // 1-KiB DMA pieces per wave per k-tile
-  static constexpr int CPR_MN = ROWS / 8;       // 16-byte chunks per k-row of an MN-major tile
+  static constexpr int BYTES = ROWS * KB * 2;           // both layouts
+  static constexpr int NP = BYTES / 1024 / NWAVES;      // 1-KiB DMA pieces per wave per k-tile
+  static constexpr int CPR_MN = ROWS / 8;               // 16-byte chunks per k-row of an MN-major tile
+  static constexpr int KROWB = KB * 2;                  // bytes per row of a K-major tile
+  static constexpr int CPRK = KB / 8;                   // 16-byte chunks per row of a K-major tile
+  static constexpr int RPP = 1024 / KROWB;              // K-major rows per DMA piece
+  // XOR swizzle of the chunk index of K-major row `row`: 256 / KROWB rows share a 256-byte bank line, the 16 rows
+  // of one ds_read_b128 lane group must land on 16 different 16-byte slots
+  static __device__ __forceinline__ int swz(int row) {
+    if constexpr (KB == 64) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+  }
   // rotation (in 16-byte chunks) of k-row k of an MN-major tile, chosen so that the four k-rows one
   // ds_read_b64_tr_b16 half-wave touches land on four different 64-byte bank groups:
   //   256- / 512-byte rows start on a bank-line boundary      -> 4 * (k & 3)
@@ -78,9 +87,9 @@ __device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int&
 }
 
 // ROLE: 0 plain, 1 conv-fwd rows, 2 conv-dgrad rows (K-major), 3 conv-wgrad (MN-major, k = output pixel)
-template <int ROWS, int LAYOUT, int ROLE, int NWAVES>
+template <int ROWS, int LAYOUT, int ROLE, int NWAVES, int KB = 64>
 struct DmaLoader {
-  using G = Geo<ROWS, NWAVES>;
+  using G = Geo<ROWS, NWAVES, KB>;
   static constexpr int NP = G::NP;
   unsigned off0[NP];
   int c0[NP], c1[NP], c2[NP];
@@ -102,8 +111,8 @@ struct DmaLoader {
     for (int i = 0; i < NP; ++i) {
       const int pi = wave + NWAVES * i;
       if constexpr (LAYOUT == HTRVT_KMAJOR) {
-        const int rl = pi * 8 + (lane >> 3);
-        const int cg = (lane & 7) ^ ((rl >> 1) & 7);
+        const int rl = pi * G::RPP + lane / G::CPRK;
+        const int cg = (lane % G::CPRK) ^ G::swz(rl);
         const int row = row0 + rl;
         ok[i] = row < rows_total;
         c2[i] = cg * 8;
@@ -223,19 +232,19 @@ struct DmaLoader {
           off += (unsigned)(((b * p.Hi + hi) * p.Wi + wi) * p.Ci) * 2;
         }
       }
-      const unsigned voff = v ? off : OOB;
+      const unsigned voff = (v && k0 < kend) ? off : OOB;   // k0 >= kend: a zero-fill piece past the last k-tile
       dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_tile + (wave + NWAVES * i) * 1024), voff);
     }
   }
 };
 
-template <int ROWS, int LAYOUT>
+template <int ROWS, int LAYOUT, int KB = 64>
 __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, int lane) {
-  using G = Geo<ROWS>;
+  using G = Geo<ROWS, 8, KB>;
   if constexpr (LAYOUT == HTRVT_KMAJOR) {
     const int row = rb * 32 + (lane & 31);
     const int chunk = 2 * s + (lane >> 5);
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * G::KROWB + ((chunk ^ G::swz(row)) << 4));
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
@@ -676,7 +685,9 @@ int pick_bn(const HtrvtGemmDesc* d) {
   const bool fused = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   // 256x256 tiles move 14 % fewer operand bytes per FLOP through the (per-CU, ~70 GB/s) LDS-DMA path than 256x192
   // (256x384 would save 29 % but its 192 accumulator registers per wave do not fit beside the loader state)
-  if (N % 256 == 0 && !fused && (d->tile == 0 || d->tile == 6)) return 256;
+  // measured (tools/bench_gemm.py --tiles 3 4 6): +8 % on the N=768 conv wgrad, +20 % on 4096^3, but -20 % where the
+  // tile count stops filling whole rounds of 256 CUs (N=768 / 2304 Linear layers) -> conv wgrad and explicit only
+  if (N % 256 == 0 && !fused && (d->tile == 6 || (d->tile == 0 && d->gather == HTRVT_GATHER_CONV_WGRAD))) return 256;
   if (N <= 64) return 64;
   if (N <= 128) return 128;
   const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;

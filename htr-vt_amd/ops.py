@@ -12,8 +12,11 @@ import torch
 from . import _lib
 from ._lib import BF16, F32, GATHER_CONV_DGRAD, GATHER_CONV_FWD, GATHER_CONV_WGRAD, KMAJOR, MNMAJOR, GemmDesc, check, lib
 
+import os
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+_ENV_TILE = int(os.environ.get("HTRVT_GEMM_TILE", "0"))
 
 
 def dt(dtype: torch.dtype) -> int:
@@ -85,7 +88,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.act = act
     d.c_f32 = 1 if c_f32 else 0
     d.accumulate = 1 if accumulate else 0
-    d.tile = tile
+    d.tile = tile or _ENV_TILE     # HTRVT_GEMM_TILE: force a kernel variant (A/B runs, tests of non-default variants)
     d.bias = ptr(bias)
     d.preact = ptr(preact)
     d.residual = ptr(residual)

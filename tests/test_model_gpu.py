@@ -197,3 +197,32 @@ def test_bf16_gradients_track_f32_and_fused_equals_unfused():
     print("fused vs unfused bf16 worst cosine", worst_fu, "| bf16 vs f32 worst cosine", worst_32)
     assert worst_fu > 0.995
     assert worst_32 > 0.85
+
+
+@pytest.mark.parametrize("tag,kw,W,nb,B", [
+    ("cfg4 long line 64x2048 (N=512)", dict(embed_dim=768, depth=4, num_heads=6), 2048, 80, 2),
+    ("cfg5 d512/12L/8h nb_cls 90", dict(embed_dim=512, depth=12, num_heads=8), 1024, 90, 2),
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_other_baseline_configs_step(tag, kw, W, nb, B, dtype):
+    """BASELINE.json configs 4 and 5: forward parity against the CPU oracle (float32: 1e-3) and a finite
+    fwd + CTC + bwd step on both arithmetic paths"""
+    import htrvt_amd
+    cfg = O.Config(nb, (64, W), **kw)
+    sd = O.init_state_dict(cfg, seed=9, randomize_affine=True)
+    x, targets, lengths = O.synthetic_batch(B, 64, W, nb, cfg.num_patches, seed=4)
+    m = _model(cfg, sd, dtype=dtype)
+    m.eval()
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        ref = O.forward(sd, cfg, x, train=False)
+    err = (y - ref).abs().max().item()
+    print(tag, dtype, "eval max-abs vs oracle", err)
+    assert err < (LOGIT_TOL if dtype == torch.float32 else 0.25)
+    m.train()
+    torch.manual_seed(1)
+    yt = m(x.cuda(), 0.4, 8, use_masking=True)
+    loss = htrvt_amd.ctc_loss(yt, targets, lengths)
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    assert all(torch.isfinite(p.grad).all().item() for p in m.parameters() if p.requires_grad)

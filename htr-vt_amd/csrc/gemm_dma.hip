@@ -1,673 +1,17 @@
-// gemm_dma.hip -- bfloat16 throughput path of htrvt_gemm: 256 x BN x 64 tiles,
-// 512 threads = 8 waves (4 along M x 2 along N, each 64 x BN/2), operand tiles
-// moved global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging,
-// no ds_write), double buffered: the DMA of k-tile t+1 is in flight while k-tile t
-// is multiplied (v_mfma_f32_32x32x16_bf16), one barrier per k-tile.
-//
-// Why buffer loads: an out-of-range byte offset makes the hardware deliver zeros,
-// so image-border taps of the implicit-GEMM convolutions (zero padding), M/N/K
-// tails and strided-dgrad "holes" cost no branch -- an invalid 16-byte chunk simply
-// gets the offset 0x80000000 (every operand is < 2 GiB).
-//
-// LDS images (DMA writes lane-linear: base + 16*lane, so any swizzle is applied to
-// the per-lane SOURCE chunk and again on the read):
-//   K-major operand  : [rows][128 B], 16-byte chunk c stored at c ^ ((row>>1) & 7) -> ds_read_b128, conflict-free
-//                      (two 128-B rows share a 256-B bank line: the 16 rows of a ds_read_b128 lane group hit 16 slots)
-//   MN-major operand : [64 k][rows*2 B], chunk c stored at (c + 4*(k&3)) mod CPR  -> ds_read_b64_tr_b16 (transpose)
+// gemm_dma.hip -- host-side selection of the bfloat16 LDS-DMA GEMM kernel variant (kernels: gemm_dma_impl.h,
+// instantiated per N-tile width in gemm_dma_bn*.hip).
 #include "gemm_common.h"
 
 using namespace htrvt;
 
+namespace htrvt {
+int gemm_dma_dispatch_bn64(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
+int gemm_dma_dispatch_bn128(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
+int gemm_dma_dispatch_bn192(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
+int gemm_dma_dispatch_bn256(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
+}  // namespace htrvt
+
 namespace {
-
-constexpr int BK = 64;
-constexpr unsigned OOB = 0x80000000u;
-
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-
-// One LDS-DMA piece: 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB).  Inline asm on purpose: hipcc would
-// otherwise order every later ds_read behind the DMA with s_waitcnt vmcnt(0) (it cannot prove the two LDS stages
-// disjoint), which serialises load and MFMA.  The kernel counts these loads itself (vmcnt before the barrier).
-__device__ __forceinline__ void dma16(const i32x4_t& rsrc, unsigned lds_addr, unsigned voff) {
-  unsigned keep;
-  asm volatile(
-      "s_nop 4\n\t"
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(lds_addr), "s"(rsrc)
-      : "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
-  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
-}
-
-template <int ROWS, int NWAVES = 8, int KB = 64>   // KB = k-tile depth in elements (64, or 32 for the deep pipeline)
-struct Geo {
-  static constexpr int BYTES = ROWS * KB * 2;           // both layouts
-  static constexpr int NP = BYTES / 1024 / NWAVES;      // 1-KiB DMA pieces per wave per k-tile
-  static constexpr int CPR_MN = ROWS / 8;               // 16-byte chunks per k-row of an MN-major tile
-  static constexpr int KROWB = KB * 2;                  // bytes per row of a K-major tile
-  static constexpr int CPRK = KB / 8;                   // 16-byte chunks per row of a K-major tile
-  static constexpr int RPP = 1024 / KROWB;              // K-major rows per DMA piece
-  // XOR swizzle of the chunk index of K-major row `row`: 256 / KROWB rows share a 256-byte bank line, the 16 rows
-  // of one ds_read_b128 lane group must land on 16 different 16-byte slots
-  static __device__ __forceinline__ int swz(int row) {
-    if constexpr (KB == 64) return (row >> 1) & 7;
-    else return (row >> 2) & 3;
-  }
-  // rotation (in 16-byte chunks) of k-row k of an MN-major tile, chosen so that the four k-rows one
-  // ds_read_b64_tr_b16 half-wave touches land on four different 64-byte bank groups:
-  //   256- / 512-byte rows start on a bank-line boundary      -> 4 * (k & 3)
-  //   384-byte rows start at 0 / 128 alternately (k & 1)       -> 4 * ((k >> 1) & 1)   (exhaustive search)
-  static __device__ __forceinline__ int rot(int k) {
-    if constexpr (ROWS == 192) return 4 * ((k >> 1) & 1);
-    else if constexpr (ROWS >= 128) return 4 * (k & 3);
-    else return 0;
-  }
-};
-
-__device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int& ho, int& wo) {
-  if (p.howo_shift >= 0) {
-    b = m >> p.howo_shift;
-    const int r = m & ((1 << p.howo_shift) - 1);
-    ho = r >> p.wo_shift;
-    wo = r & ((1 << p.wo_shift) - 1);
-  } else {
-    const int hw = p.Ho * p.Wo;
-    b = m / hw;
-    const int r = m - b * hw;
-    ho = r / p.Wo;
-    wo = r - ho * p.Wo;
-  }
-}
-
-// ROLE: 0 plain, 1 conv-fwd rows, 2 conv-dgrad rows (K-major), 3 conv-wgrad (MN-major, k = output pixel)
-template <int ROWS, int LAYOUT, int ROLE, int NWAVES, int KB = 64>
-struct DmaLoader {
-  using G = Geo<ROWS, NWAVES, KB>;
-  static constexpr int NP = G::NP;
-  unsigned off0[NP];
-  int c0[NP], c1[NP], c2[NP];
-  bool ok[NP];
-  i32x4_t rsrc;
-  unsigned ld2;  // leading dimension in bytes
-  // conv row gather: byte offset of (pixel reached through the current tap, this lane's chunk) or OOB -- refreshed
-  // only when the k-loop enters a new tap, so a k-tile inside a tap costs one add per piece
-  unsigned tapoff[NP];
-  int cur_ti;
-
-  __device__ __forceinline__ void init(const KParams& p, const char* base, long long ld, int row0, int rows_total, int wave,
-                                       int lane) {
-    const unsigned long long ba = (unsigned long long)base;  // raw buffer, stride 0, 2 GiB of records
-    rsrc = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
-    ld2 = (unsigned)(ld * 2);
-    cur_ti = -1;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int pi = wave + NWAVES * i;
-      if constexpr (LAYOUT == HTRVT_KMAJOR) {
-        const int rl = pi * G::RPP + lane / G::CPRK;
-        const int cg = (lane % G::CPRK) ^ G::swz(rl);
-        const int row = row0 + rl;
-        ok[i] = row < rows_total;
-        c2[i] = cg * 8;
-        if constexpr (ROLE == 0) {
-          off0[i] = (unsigned)row * ld2 + cg * 16;
-          c0[i] = c1[i] = 0;
-        } else if constexpr (ROLE == 1) {
-          int b, ho, wo;
-          const int hw = p.Ho * p.Wo;
-          b = row / hw;
-          const int r = row - b * hw;
-          ho = r / p.Wo;
-          wo = r - ho * p.Wo;
-          off0[i] = (unsigned)b * p.Hi * p.Wi * p.Ci * 2;
-          c0[i] = ho * p.sh - p.ph;
-          c1[i] = wo * p.sw - p.pw;
-        } else {  // input pixel of this row (all pixels, or the pixels of one stride-parity class)
-          const int hw = p.Hq * p.Wq;
-          const int b = row / hw, r = row - b * hw;
-          int hi = r / p.Wq, wi = r - hi * p.Wq;
-          if (p.cls_h >= 0) {
-            hi = hi * p.sh + p.cls_h;
-            wi = wi * p.sw + p.cls_w;
-          }
-          off0[i] = (unsigned)b * p.Ho * p.Wo * p.Co * 2;
-          c0[i] = hi + p.ph;
-          c1[i] = wi + p.pw;
-        }
-      } else {
-        const int s = pi * 64 + lane;
-        const int krow = s / G::CPR_MN, cl = s - krow * G::CPR_MN;
-        int cg = cl - G::rot(krow);
-        if (cg < 0) cg += G::CPR_MN;
-        const int col = row0 + cg * 8;
-        c2[i] = krow;
-        if constexpr (ROLE == 0) {
-          ok[i] = col < rows_total;
-          off0[i] = (unsigned)col * 2;
-          c0[i] = c1[i] = 0;
-        } else {  // ROLE 3: col = tap*Cpad + ci
-          const int tap = col / p.Cpad, ci = col - tap * p.Cpad;
-          const int dy = tap / p.kw, dx = tap - dy * p.kw;
-          ok[i] = (col < rows_total) && (ci < p.Ci);
-          off0[i] = (unsigned)ci * 2;
-          c0[i] = dy - p.ph;
-          c1[i] = dx - p.pw;
-        }
-      }
-    }
-  }
-
-  // kmap: plain K-major operand (the packed conv weights) whose k runs over a SELECTED tap list
-  template <bool KMAP = false>
-  __device__ __forceinline__ void issue(const KParams& p, unsigned lds_tile, int k0, int kend, int wave) {
-    int tap_dy = 0, tap_dx = 0, cbase = k0;
-    if constexpr (ROLE == 1 || ROLE == 2 || KMAP) {
-      const int ti = k0 / p.Cpad;
-      const int tap = p.tapsel[ti];
-      cbase = k0 - ti * p.Cpad;
-      tap_dy = tap / p.kw;
-      tap_dx = tap - tap_dy * p.kw;
-      if constexpr (KMAP) cbase += tap * p.Cpad;  // column of the packed weight matrix
-      if constexpr (ROLE == 1 || ROLE == 2) {
-        if (ti != cur_ti) {  // wave-uniform: entering a new tap
-          cur_ti = ti;
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            bool v = ok[i];
-            unsigned off = off0[i];
-            if constexpr (ROLE == 1) {
-              const int hi = c0[i] + tap_dy, wi = c1[i] + tap_dx;
-              v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-              off += (unsigned)((hi * p.Wi + wi) * p.Ci + c2[i]) * 2;
-            } else {
-              const int th = c0[i] - tap_dy, tw = c1[i] - tap_dx;
-              const int ho = th >> (p.sh - 1), wo = tw >> (p.sw - 1);
-              v = v && (th >= 0) && (tw >= 0) && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0) && (ho < p.Ho) &&
-                  (wo < p.Wo);
-              off += (unsigned)((ho * p.Wo + wo) * p.Co + c2[i]) * 2;
-            }
-            tapoff[i] = v ? off : OOB;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      bool v = ok[i];
-      unsigned off = off0[i];
-      if constexpr (LAYOUT == HTRVT_KMAJOR) {
-        if constexpr (ROLE == 0) {
-          v = v && (k0 + c2[i] < kend);
-          off += (unsigned)(KMAP ? cbase : k0) * 2;
-        } else {  // ROLE 1 / 2: cached tap offset + channel offset; an OOB base stays OOB (adds < 2^16)
-          const int cvalid = ROLE == 1 ? p.Ci : p.Co;
-          v = (cbase + c2[i] < cvalid);
-          off = tapoff[i] + (unsigned)cbase * 2;
-        }
-      } else {
-        const int k = k0 + c2[i];
-        v = v && (k < kend);
-        if constexpr (ROLE == 0) {
-          off += (unsigned)k * ld2;
-        } else if (p.wo_shift >= 6) {
-          // Wo is a power of two >= 64 and k0 is a multiple of 64: the whole k-tile lies in ONE output row, so
-          // (b, ho, wo0) are scalars and only the column varies per lane
-          const int bq = k0 >> p.howo_shift, rq = k0 & ((1 << p.howo_shift) - 1);
-          const int hoq = rq >> p.wo_shift, wo0 = rq & ((1 << p.wo_shift) - 1);
-          const int hi = hoq * p.sh + c0[i], wi = (wo0 + c2[i]) * p.sw + c1[i];
-          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-          off += (unsigned)(((bq * p.Hi + hi) * p.Wi + wi) * p.Ci) * 2;
-        } else {
-          int b, ho, wo;
-          pix_decode(p, k, b, ho, wo);
-          const int hi = ho * p.sh + c0[i], wi = wo * p.sw + c1[i];
-          v = v && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-          off += (unsigned)(((b * p.Hi + hi) * p.Wi + wi) * p.Ci) * 2;
-        }
-      }
-      const unsigned voff = (v && k0 < kend) ? off : OOB;   // k0 >= kend: a zero-fill piece past the last k-tile
-      dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_tile + (wave + NWAVES * i) * 1024), voff);
-    }
-  }
-};
-
-template <int ROWS, int LAYOUT, int KB = 64>
-__device__ __forceinline__ bf16x8_t frag_read(const char* lds, int rb, int s, int lane) {
-  using G = Geo<ROWS, 8, KB>;
-  if constexpr (LAYOUT == HTRVT_KMAJOR) {
-    const int row = rb * 32 + (lane & 31);
-    const int chunk = 2 * s + (lane >> 5);
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * G::KROWB + ((chunk ^ G::swz(row)) << 4));
-    return __builtin_bit_cast(bf16x8_t, v);
-  } else {
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
-    int chunk = rb * 4 + 2 * (g & 1) + (pp >> 1) + G::rot(q);
-    if (chunk >= G::CPR_MN) chunk -= G::CPR_MN;
-    const int krow = 16 * s + 8 * h + q;
-    const char* a0 = lds + krow * (ROWS * 2) + chunk * 16 + (pp & 1) * 8;
-    typedef __attribute__((address_space(3))) s16x4_t* lptr;
-    const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
-    const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * (ROWS * 2)));
-    const s16x8_t r = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    return __builtin_bit_cast(bf16x8_t, r);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// bf16 epilogue staged through LDS: accumulators -> (alpha, bias) -> bf16, written column-major into the dead
-// operand buffers; read back transposed (ds_read_b64_tr_b16) so that every lane owns 8 consecutive columns of
-// one row: GELU / GELU' / residual / pre-activation traffic and the C store are all 16-byte, row-contiguous.
-// (A per-lane 2-byte store epilogue is store-issue bound: 96 store instructions per wave for a 64x96 block.)
-// ---------------------------------------------------------------------------------------------
-template <int BM>
-struct Stg {
-  static constexpr int CST = BM * 2 + 8;  // bytes per staged column (BM rows + pad: conflict-free ds_write_b64)
-};
-
-__device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-
-// DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
-template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD>
-__device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
-                                                int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
-  constexpr int CST = Stg<BM>::CST;
-  constexpr int NWAVES = NW_TOTAL, NTH = NW_TOTAL * 64, NWM = BM / 64;
-  // tiles wider than 192 columns are staged in two passes (the column-major staging image must fit the LDS)
-  constexpr int PASSES = BN > 192 ? 2 : 1;
-  constexpr int TNP = TN / PASSES, BNS = BN / PASSES;
-  const int h = lane >> 5, cl = lane & 31;
-  float cs1[TN], cs2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
-  constexpr int GROUPS = BNS / 32;            // groups of 4 chunks (32 columns) per row
-  constexpr int ITEMS = (BM / 16) * GROUPS;   // wave-level items: 16 rows x 32 columns
-  const int lr = lane & 15, lg = lane >> 4;
-  const int q = lr >> 2, pp = lr & 3;
-  typedef __attribute__((address_space(3))) s16x4_t* lptr;
-  // When the wave count is a multiple of the column groups every wave keeps ONE column group and walks the row
-  // blocks: a lane then owns 8 fixed columns, which lets it accumulate per-column BatchNorm-backward sums.
-  constexpr bool FIXED_COLS = (NWAVES % GROUPS) == 0;
-  constexpr int RB_STEP = FIXED_COLS ? NWAVES / GROUPS : 1;
-  const bool bnb = DGRAD && FIXED_COLS && PASSES == 1 && p.bnb_partial[0] != nullptr;
-  const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
-  float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = bmu[t][e] = brs[t][e] = 0.f;
-  if (bnb) {
-    const int nc = n0 + (wave % GROUPS) * 32 + lg * 8;
-    if (nc < p.N) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bmu[0][e] = p.bnb_mean[0][nc + e];
-        brs[0][e] = p.bnb_rstd[0][nc + e];
-        if (bnb2) {
-          bmu[1][e] = p.bnb_mean[1][nc + e];
-          brs[1][e] = p.bnb_rstd[1][nc + e];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
-  if (pass > 0) __syncthreads();   // the previous pass has drained the staging image
-  // ---- phase 1: registers -> LDS (column-major bf16); loader waves hold no accumulators ----
-  if (active) {
-#pragma unroll
-  for (int jp = 0; jp < TNP; ++jp) {
-    const int j = pass * TNP + jp;
-    const int ccol = (wn * TNP + jp) * 32 + cl;          // column in the staging image
-    const int n = n0 + (wn * TN + j) * 32 + cl;
-    const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int crow = (wm * 2 + i) * 32 + 8 * g + 4 * h;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = acc[i][j][4 * g + r];  // rows >= M and cols >= N hold exact zeros (zero-filled operands)
-          cs1[j] += a;
-          cs2[j] += a * a;
-          v[r] = a * p.alpha + bias;
-        }
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(smem + ccol * CST + crow * 2) = o;
-      }
-    }
-  }
-  }
-  __syncthreads();
-  // ---- phase 2: LDS -> (act / residual) -> global, 16 B per lane, 4 lanes = 64 contiguous bytes of one row ----
-  // Items are processed U at a time: all global loads of the U items (residual, ReLU source, BN inputs, saved
-  // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
-  // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
-  constexpr int U = DGRAD ? 2 : 4;
-  const bool has_res = p.residual != nullptr, has_relu = DGRAD && p.relu_src != nullptr, has_pre_in = !DGRAD && p.act == 2;
-  for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
-    long long o[U];
-    bool ok[U];
-    uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int id = id0 + u * NWAVES;
-      int rbk, cg;
-      if constexpr (FIXED_COLS) {
-        cg = wave % GROUPS;
-        rbk = (wave / GROUPS) + ((id - wave) / NWAVES) * RB_STEP;
-      } else {
-        rbk = id / GROUPS;
-        cg = id - rbk * GROUPS;
-      }
-      const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
-      int m = m0 + crow0 + lr;
-      const int half = ccol0 / (TNP * 32);                 // which wave column (wn) staged this column
-      const int n = n0 + (half * TN + pass * TNP) * 32 + (ccol0 - half * TNP * 32);
-      ok[u] = id < ITEMS && m < p.M && n < p.N;
-      if (p.cls_h >= 0) {  // class row -> input-pixel row of the NHWC gradient
-        const int hw = p.Hq * p.Wq;
-        const int b = m / hw, r = m - b * hw;
-        const int hq = r / p.Wq, wq = r - hq * p.Wq;
-        m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
-      }
-      o[u] = ok[u] ? coff + (long long)m * p.ldc + n : coff;   // coff itself is a valid element of every operand
-      if (has_res) rres[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + o[u]);
-      if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.relu_src) + o[u]);
-      if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.preact) + o[u]);
-      if (bnb) rbx[0][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + o[u]);
-      if (bnb2) rbx[1][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + o[u]);
-      const int idc = id < ITEMS ? id : wave;  // clamp the LDS address of a tail item
-      int rbk2, cg2;
-      if constexpr (FIXED_COLS) {
-        cg2 = cg;
-        rbk2 = (wave / GROUPS) + ((idc - wave) / NWAVES) * RB_STEP;
-      } else {
-        rbk2 = idc / GROUPS;
-        cg2 = idc - rbk2 * GROUPS;
-      }
-      const char* a0 = smem + (cg2 * 32 + lg * 8 + q) * CST + (rbk2 * 16 + 4 * pp) * 2;
-      const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
-      const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
-      raw[u] = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float v[8] = {bf16lo(raw[u].x), bf16hi(raw[u].x), bf16lo(raw[u].y), bf16hi(raw[u].y),
-                    bf16lo(raw[u].z), bf16hi(raw[u].z), bf16lo(raw[u].w), bf16hi(raw[u].w)};
-      bool touched = false;
-      if (has_pre_in) {
-        const uint4 pr = rpre[u];
-        const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
-                            bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
-        touched = true;
-      } else if (p.preact != nullptr) {
-        if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.preact) + o[u]) = raw[u];
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        touched = true;
-      }
-      if (has_res) {
-        const uint4 rr = rres[u];
-        v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
-        v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
-        touched = true;
-      }
-      if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
-        const uint4 rs = rrelu[u];
-        const float y[8] = {bf16lo(rs.x), bf16hi(rs.x), bf16lo(rs.y), bf16hi(rs.y),
-                            bf16lo(rs.z), bf16hi(rs.z), bf16lo(rs.w), bf16hi(rs.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-        touched = true;
-      }
-      if (bnb) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          if (t == 1 && !bnb2) break;
-          const uint4 xr = rbx[t][u];
-          const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
-                              bf16lo(xr.z), bf16hi(xr.z), bf16lo(xr.w), bf16hi(xr.w)};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float gv = ok[u] ? v[e] : 0.f;
-            bs1[t][e] += gv;
-            bs2[t][e] += gv * ((x[e] - bmu[t][e]) * brs[t][e]);
-          }
-        }
-      }
-      uint4 out = raw[u];
-      if (touched) {
-        out.x = pack_bf16x2(v[0], v[1]);
-        out.y = pack_bf16x2(v[2], v[3]);
-        out.z = pack_bf16x2(v[4], v[5]);
-        out.w = pack_bf16x2(v[6], v[7]);
-      }
-      if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o[u]) = out;
-    }
-  }
-  }  // pass
-  if (p.colstats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + BNS * CST);  // [NWM][BN][2], behind the staged tile
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
-      const float s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (h == 0 && active) {
-        const int c = (wn * TN + j) * 32 + cl;
-        red[(wm * BN + c) * 2 + 0] = s1;
-        red[(wm * BN + c) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < BN; c += NTH) {
-      const int n = n0 + c;
-      if (n < p.N) {
-        float* dst = p.colstats + (long long)tile_m * 2 * p.N;
-        float a = 0.f, q2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWM; ++w) {
-          a += red[(w * BN + c) * 2];
-          q2 += red[(w * BN + c) * 2 + 1];
-        }
-        dst[n] = a;
-        dst[p.N + n] = q2;
-      }
-    }
-  }
-  if constexpr (FIXED_COLS) {
-    if (bnb) {  // workgroup-uniform
-      float* red2 = reinterpret_cast<float*>(smem + BNS * CST + NWM * BN * 8);  // [2 sets][RB_STEP][BN][2]
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-          for (int sft = 1; sft < 16; sft <<= 1) {
-            bs1[t][e] += __shfl_xor(bs1[t][e], sft, 64);
-            bs2[t][e] += __shfl_xor(bs2[t][e], sft, 64);
-          }
-        }
-      if (lr == 0) {
-        const int c0 = (wave % GROUPS) * 32 + lg * 8, slab = wave / GROUPS;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            red2[((t * RB_STEP + slab) * BN + c0 + e) * 2 + 0] = bs1[t][e];
-            red2[((t * RB_STEP + slab) * BN + c0 + e) * 2 + 1] = bs2[t][e];
-          }
-      }
-      __syncthreads();
-      for (int c = threadIdx.x; c < BN; c += NTH) {
-        const int n = n0 + c;
-        if (n < p.N) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            if (t == 1 && !bnb2) break;
-            float a = 0.f, q2 = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < RB_STEP; ++sl) {
-              a += red2[((t * RB_STEP + sl) * BN + c) * 2];
-              q2 += red2[((t * RB_STEP + sl) * BN + c) * 2 + 1];
-            }
-            float* dst = p.bnb_partial[t] + (long long)(p.bnb_tile0 + tile_m) * 2 * p.N;
-            dst[n] = a;
-            dst[p.N + n] = q2;
-          }
-        }
-      }
-    }
-  }
-}
-
-// SPEC = 0: every wave issues its share of the DMA, then multiplies (NTH = 2*BM).
-// SPEC = 1: wave specialisation -- 4 extra loader waves own ALL address arithmetic + DMA issue of the next k-tile
-//           while the BM/32 consumer waves run nothing but ds_read + MFMA; one workgroup barrier per k-tile.
-template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
-__global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KParams p) {
-  using T = bf16_t;
-  constexpr int NWC = BM / 32;                 // consumer (MFMA) waves
-  constexpr int NWL = SPEC ? 4 : NWC;          // waves that issue DMA
-  constexpr int NW_TOTAL = NWC + (SPEC ? 4 : 0);
-  constexpr int NTH = NW_TOTAL * 64;
-  constexpr int TM = 2, TN = BN / 64;
-  constexpr int A_BYTES = Geo<BM>::BYTES, B_BYTES = Geo<BN>::BYTES;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int id = blockIdx.x;
-  if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
-  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int z = blockIdx.z;
-  const char* Ab = p.A;
-  const char* Bb = p.B;
-  int kbeg = 0, kend = p.K;
-  long long coff = 0;
-  if (p.split_k > 1) {
-    kbeg = z * p.kchunk;
-    kend = min(p.K, kbeg + p.kchunk);
-  } else {
-    const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
-    Ab += (zo * p.sA_o + zi * p.sA_i) * 2;
-    Bb += (zo * p.sB_o + zi * p.sB_i) * 2;
-    coff = zo * p.sC_o + zi * p.sC_i;
-  }
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool consumer = wave < NWC;
-  const bool loader = SPEC ? !consumer : true;
-  const int lw = SPEC ? (wave - NWC) & 3 : wave;   // index among the DMA-issuing waves
-  const int wm = (wave >> 1) % (BM / 64), wn = wave & 1;
-
-  DmaLoader<BM, AL, GATHER, NWL> la;
-  DmaLoader<BN, BL, 0, NWL> lb;
-  la.init(p, Ab, p.lda, m0, p.M, lw, lane);  // unconditional: the descriptors must stay provably wave-uniform (SGPRs)
-  lb.init(p, Bb, p.ldb, n0, p.N, lw, lane);
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nkt = (kend - kbeg + BK - 1) / BK;
-  const unsigned lds0 = lds_addr_of(smem);
-  constexpr bool KMAP = (GATHER == 1 || GATHER == 2);
-  if (nkt > 0 && loader) {
-    la.issue(p, lds0, kbeg, kend, lw);
-    lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, lw);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    const unsigned nxt = lds0 + ((kt + 1) & 1) * STAGE;
-    if (loader && kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
-      la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, lw);
-      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, lw);
-    }
-    if (consumer) {
-      const char* sa = cur;
-      const char* sb = cur + A_BYTES;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
-  if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
-  else
-    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
-                                               smem, consumer);
-}
-
-template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
-int launch(const KParams& p, int zdim, hipStream_t st) {
-  constexpr int NTH = BM * 2 + SPEC * 256;
-  constexpr int smem = 2 * (Geo<BM>::BYTES + Geo<BN>::BYTES);
-  static bool attr_done = false;
-  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER, SPEC>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
-      return -2;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1, zdim), dim3(NTH), smem, st, p);
-  const int rc = check_launch("gemm_dma_kernel");
-  return rc ? rc : 1;
-}
-
-template <int BM, int BN, int SPEC>
-int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st) {
-  const int al = d->a_layout, bl = d->b_layout, g = d->gather;
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, SPEC>(p, zdim, st);
-  return 0;
-}
 
 constexpr int BM_ = 256;
 
@@ -743,15 +87,11 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.howo_shift = b;
     }
   }
-  if (bn == 256) return dispatch<256, 256, 0>(d, p, zdim, st);
-  if (use_loader_waves(d)) {
-    if (bn == 64) return dispatch<256, 64, 1>(d, p, zdim, st);
-    if (bn == 128) return dispatch<256, 128, 1>(d, p, zdim, st);
-    return dispatch<256, 192, 1>(d, p, zdim, st);
-  }
-  if (bn == 64) return dispatch<256, 64, 0>(d, p, zdim, st);
-  if (bn == 128) return dispatch<256, 128, 0>(d, p, zdim, st);
-  return dispatch<256, 192, 0>(d, p, zdim, st);
+  const bool spec = use_loader_waves(d);
+  if (bn == 256) return gemm_dma_dispatch_bn256(d, p, zdim, st, false);
+  if (bn == 64) return gemm_dma_dispatch_bn64(d, p, zdim, st, spec);
+  if (bn == 128) return gemm_dma_dispatch_bn128(d, p, zdim, st, spec);
+  return gemm_dma_dispatch_bn192(d, p, zdim, st, spec);
 }
 
 }  // namespace htrvt

@@ -1,0 +1,10 @@
+// gemm_dma_bn256.hip -- instantiations of the LDS-DMA GEMM kernel for N tiles of 256 columns (own translation
+// unit: hipcc spends ~1 minute per dozen kernel variants, the Makefile builds the units in parallel)
+#include "gemm_dma_impl.h"
+
+namespace htrvt {
+int gemm_dma_dispatch_bn256(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st, bool spec) {
+  (void)spec;
+  return dispatch<256, 256, 0>(d, p, zdim, st);
+}
+}  // namespace htrvt

@@ -1,0 +1,11 @@
+// gemm_dma_bn64.hip -- instantiations of the LDS-DMA GEMM kernel for N tiles of 64 columns (own translation
+// unit: hipcc spends ~1 minute per dozen kernel variants, the Makefile builds the units in parallel)
+#include "gemm_dma_impl.h"
+
+namespace htrvt {
+int gemm_dma_dispatch_bn64(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st, bool spec) {
+  if (spec) return dispatch<256, 64, 1>(d, p, zdim, st);
+  (void)spec;
+  return dispatch<256, 64, 0>(d, p, zdim, st);
+}
+}  // namespace htrvt

@@ -72,6 +72,32 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
 
+  // Fast path (wave-uniform): float32 C, the wave's whole TM x TN block inside the matrix, nothing but alpha / bias /
+  // store-or-atomic-add -- attention scores, weight-gradient split-K.  No per-element predicates or branches.
+  if (active && p.c_f32 && p.act == 0 && p.preact == nullptr && p.residual == nullptr && p.colstats == nullptr &&
+      mrow0 + TM * 32 <= p.M && ncol0 + TN * 32 <= p.N) {
+    float* Cf = reinterpret_cast<float*>(Cb) + coff;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32 + cl;
+        const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+        float* col = Cf + (long long)(mrow0 + i * 32 + 4 * h) * p.ldc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r] * p.alpha + bias;
+          float* dst = col + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc;
+          if (p.accumulate)
+            atomicAdd(dst, v);
+          else
+            *dst = v;
+        }
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
+    ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=1)
     return ap.parse_args()
@@ -112,6 +114,8 @@ def main():
     else:
         model.train()
         tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world, use_collectives=use_dist)
+        tr.engine.fuse_bn_backward = not args.no_fuse_bn
+        tr.engine.overlap_wgrad = not args.no_overlap_wgrad
 
         def one_step():
             return tr.step(x, tg, tl, keep_mask=keep)

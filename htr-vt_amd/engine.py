@@ -158,7 +158,8 @@ class Engine:
         tiles = ((Mo + bm - 1) // bm) * ((No + bn - 1) // bn)
         flops = 2.0 * Mo * No * Kred
         best, best_t = 1, None
-        for s in range(1, 129):
+        # multiples of 8 let the kernel keep all tiles of one K range on one XCD (shared L2); small factors otherwise
+        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, 129, 8)):
             if Kred // s < 512:
                 break
             blocks = tiles * s

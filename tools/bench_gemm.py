@@ -121,8 +121,8 @@ def main():
                                      gather=ops.GATHER_CONV_DGRAD, geom=g, Cpad=Co), args.iters)
         rows.append((tag + " dgrad", ms, fl))
         dw = torch.zeros(g.taps, Ci, Co, dtype=torch.float32, device=dev)
-        tiles = ((g.taps * Ci + 255) // 256) * ((Co + 191) // 192)
-        split = max(1, min(1024 // tiles, M // 1024, 128))
+        from htrvt_amd.engine import Engine, ModelShape
+        split = Engine(ModelShape(80, (64, 1024), 768, 4, 6), dt)._split_k(g.taps * Ci, Co, M)
         ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
                                      b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci, split_k=split,
                                      accumulate=True, c_f32=True), args.iters)
@@ -135,7 +135,7 @@ def main():
         plain("NT fc2 32768x768x3072", 32768, 768, 3072)
         nn("NN dgrad-fc1 32768x768x3072", 32768, 768, 3072)
         nn("NN dgrad-qkv 32768x768x2304", 32768, 768, 2304)
-        tn("TN wgrad-fc1 3072x768xK32768", 3072, 768, 32768, 16)
+        tn("TN wgrad-fc1 3072x768xK32768", 3072, 768, 32768, 8)
     if not args.only or "conv" in args.only:
         conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)

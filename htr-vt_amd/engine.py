@@ -151,10 +151,12 @@ class Engine:
         gemm(dy, w, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_layout=MNMAJOR, act=act, preact=preact)
         return dx
 
-    def _split_k(self, Mo, No, Kred):
+    def _split_k(self, Mo, No, Kred, conv=False):
         """split-K factor of a weight-gradient GEMM: fill the 256 CUs in whole rounds, but keep the float32
         atomic traffic (one full output tile per block, ~1.3 TB/s chip-wide) small against the MFMA time."""
         bm, bn = (256, 192) if self.dtype == torch.bfloat16 else (128, 128)
+        if conv and self.dtype == torch.bfloat16 and No % 256 == 0:
+            bn = 256      # gemm_dma.hip pick_bn(): conv weight gradients with N % 256 == 0 use 256x256 tiles
         tiles = ((Mo + bm - 1) // bm) * ((No + bn - 1) // bn)
         flops = 2.0 * Mo * No * Kred
         best, best_t = 1, None
@@ -165,6 +167,8 @@ class Engine:
             blocks = tiles * s
             rounds = (blocks + 255) // 256
             t = flops / 1.0e15 * (rounds * 256.0 / blocks) + blocks * bm * bn * 4 / 1.3e12
+            if s > 1 and s % 8:
+                t *= 1.10     # no XCD grouping of the K ranges: 4-7x the operand traffic (profiles/r01_gemm_hbm_traffic_pmc.md)
             if best_t is None or t < best_t:
                 best, best_t = s, t
         return best
@@ -250,7 +254,7 @@ class Engine:
         packed = self._zeros(g.taps, cpi, g.Co)
         gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
              a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
-             split_k=self._split_k(g.taps * cpi, g.Co, M), accumulate=True, c_f32=True)
+             split_k=self._split_k(g.taps * cpi, g.Co, M, conv=True), accumulate=True, c_f32=True)
         check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
 
     # ------------------------------------------------------------------ BatchNorm pieces

@@ -144,9 +144,13 @@ def main():
     roof = None
     if rank == 0:
         ops.PROFILE = {}
+        if not args.forward_only:
+            saved_overlap, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False   # one stream: events time ONE kernel
         for _ in range(2):
             one_step()
         torch.cuda.synchronize()
+        if not args.forward_only:
+            tr.engine.overlap_wgrad = saved_overlap
         prof, ops.PROFILE = ops.PROFILE, None
         rows = []
         for key, ent in prof.items():

@@ -142,15 +142,17 @@ def main():
 
     # ---- roofline leg: HIP events around every MFMA launch of two extra steps (not part of `value`) ----
     roof = None
+    # every rank runs the two extra steps (they contain collectives); only rank 0 records events
     if rank == 0:
         ops.PROFILE = {}
-        if not args.forward_only:
-            saved_overlap, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False   # one stream: events time ONE kernel
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
-        if not args.forward_only:
-            tr.engine.overlap_wgrad = saved_overlap
+    if not args.forward_only:
+        saved_overlap, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False   # one stream: events time ONE kernel
+    for _ in range(2):
+        one_step()
+    torch.cuda.synchronize()
+    if not args.forward_only:
+        tr.engine.overlap_wgrad = saved_overlap
+    if rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         rows = []
         for key, ent in prof.items():

@@ -66,6 +66,9 @@ PROTOTYPES = {
     "htrvt_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "htrvt_maxpool_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_conv1_bwd_rows": (i32, [i32, i32]),
+    "htrvt_conv1_bwd_row_floats": (i32, [i32]),
+    "htrvt_conv1_bwd": (i32, [vp] * 12 + [i32, i32, i32, i32, i32, vp]),
     "htrvt_conv1_wgrad_blocks": (i32, [i32, i32]),
     "htrvt_conv1_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NT) void bn_relu_maxpool_kernel(const T* __restrict
       m = t2 ? m2[j] : m;
       a = t2 ? 6u + i2[j] : a;
       o.set(j, m);
-      am[j] = a;
+      am[j] = (scale && !(m > 0.f)) ? 15u : a;   // 15: ReLU closed at the arg-max -> no gradient
       pm[j] = m2[j];  // input row 2*ho+1 is the top row of the next window
       pi[j] = i2[j];
     }

@@ -70,6 +70,7 @@ class Engine:
         self.dti = dt(dtype)
         self._packs = {}      # name -> (version key, tensors)
         self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
+        self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
         self._side, self._side_active = None, False
@@ -619,15 +620,23 @@ class Engine:
         img, c1 = sv["img"], sv["c1"]
         sc, sf, mean, rstd = sv["bn1"]
         _, Hh, W, C1 = c1.shape
-        g = torch.empty_like(c1)
-        check(lib.htrvt_maxpool_bwd(ptr(dout), ptr(sv["idx"]), ptr(c1), ptr(sc), ptr(sf), ptr(g), B, Hh, W, C1, self.dti, st),
-              "maxpool_bwd")
-        dc1, _ = self.bn_backward(g, None, c1, "patch_embed.bn1", P, G, mean, rstd)
-        del g
-        nblk = lib.htrvt_conv1_wgrad_blocks(B, 2 * Hh)
-        partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
-        check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
-                                    B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
+        if self.fuse_conv1_backward:
+            # Cin = 1: dW1, dgamma, dbeta from per-channel sums over the pooled gradient (csrc/conv1_bwd.hip)
+            partial = self._empty(lib.htrvt_conv1_bwd_rows(B, 2 * Hh), lib.htrvt_conv1_bwd_row_floats(C1), dtype=torch.float32)
+            check(lib.htrvt_conv1_bwd(ptr(img), ptr(sv["stats"]), ptr(dout), ptr(sv["idx"]), ptr(P["patch_embed.conv1.weight"]),
+                                      ptr(P["patch_embed.bn1.weight"]), ptr(mean), ptr(rstd), ptr(partial),
+                                      ptr(G["patch_embed.conv1.weight"]), ptr(G["patch_embed.bn1.weight"]),
+                                      ptr(G["patch_embed.bn1.bias"]), B, 2 * Hh, W, C1, self.dti, st), "conv1_bwd")
+        else:
+            g = torch.empty_like(c1)
+            check(lib.htrvt_maxpool_bwd(ptr(dout), ptr(sv["idx"]), ptr(c1), ptr(sc), ptr(sf), ptr(g), B, Hh, W, C1, self.dti, st),
+                  "maxpool_bwd")
+            dc1, _ = self.bn_backward(g, None, c1, "patch_embed.bn1", P, G, mean, rstd)
+            del g
+            nblk = lib.htrvt_conv1_wgrad_blocks(B, 2 * Hh)
+            partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
+            check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
+                                        B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
         self._join_side()
         self._side_active = False
         self.saved = None

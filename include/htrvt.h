@@ -172,6 +172,18 @@ int htrvt_conv1_wgrad_blocks(int B, int H);
 int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, float* dw, float* partial,
                       int B, int H, int W, int C, int dtype, void* stream);
 
+/* Backward of conv1 -> BatchNorm(train) -> ReLU -> max_pool2d(3,(2,1),1) (resnet18.py:74-77 under autograd) with
+ * respect to conv1.weight [C][9], bn1.weight and bn1.bias, in one pass over the pooled gradient dpool [B,Hp,W,C] and
+ * the arg-max bytes written by htrvt_bn_relu_maxpool (Cin = 1: the chain rule reduces to per-channel sums, see
+ * csrc/conv1_bwd.hip).  img [B,H,W] float32, stats = htrvt_img_stats output, w = conv1.weight, mean/rstd = the batch
+ * statistics saved by htrvt_bn_finalize.  partial: float32 scratch of htrvt_conv1_bwd_rows(B,H) rows x
+ * htrvt_conv1_bwd_row_floats(C) floats.  dw, dgamma, dbeta accumulate. */
+int htrvt_conv1_bwd_rows(int B, int H);
+int htrvt_conv1_bwd_row_floats(int C);
+int htrvt_conv1_bwd(const float* img, const float* stats, const void* dpool, const uint8_t* idx, const float* w,
+                    const float* gamma, const float* mean, const float* rstd, float* partial, float* dw, float* dgamma,
+                    float* dbeta, int B, int H, int W, int C, int dtype, void* stream);
+
 /* ---- weight layout helpers ----------------------------------------------------- */
 /* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */
 int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,

@@ -199,6 +199,37 @@ def test_bf16_gradients_track_f32_and_fused_equals_unfused():
     assert worst_32 > 0.85
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_conv1_backward_sums_equal_the_unfused_chain(dtype, tol):
+    """conv1/bn1/ReLU/max-pool backward computed from per-channel sums over the pooled gradient (csrc/conv1_bwd.hip)
+    against the kernel chain it replaces (arg-max scatter -> BatchNorm backward -> conv1 weight gradient) and, in
+    float32, against the float64 oracle."""
+    import htrvt_amd
+    cfg = O.Config(80, (64, 512), embed_dim=256, depth=1, num_heads=4)
+    sd = O.init_state_dict(cfg, seed=6, randomize_affine=True)
+    x, targets, lengths = O.synthetic_batch(4, 64, 512, 80, cfg.num_patches, seed=8)
+    names = ("patch_embed.conv1.weight", "patch_embed.bn1.weight", "patch_embed.bn1.bias")
+
+    def run(fuse):
+        m = _model(cfg, sd, dtype=dtype).train()
+        m._engine(torch.device("cuda", 0)).fuse_conv1_backward = fuse
+        y = m(x.cuda())
+        htrvt_amd.ctc_loss(y, targets, lengths).backward()
+        return {n: dict(m.named_parameters())[n].grad.double().cpu() for n in names}
+
+    gf, gu = run(True), run(False)
+    for n in names:
+        err = (gf[n] - gu[n]).abs().max().item() / (gu[n].abs().max().item() + 1e-30)
+        print(n, dtype, "fused vs unfused rel-to-max", err)
+        assert err < tol, (n, err)
+    if dtype == torch.float32:
+        _, _, gref, _ = O.loss_and_grads(sd, cfg, x, targets, lengths, None, dtype=torch.float64)
+        for n in names:
+            err = (gf[n] - gref[n].double()).abs().max().item() / (gref[n].abs().max().item() + 1e-30)
+            print(n, "fused vs float64 oracle rel-to-max", err)
+            assert err < 2e-2, (n, err)
+
+
 @pytest.mark.parametrize("tag,kw,W,nb,B", [
     ("cfg4 long line 64x2048 (N=512)", dict(embed_dim=768, depth=4, num_heads=6), 2048, 80, 2),
     ("cfg5 d512/12L/8h nb_cls 90", dict(embed_dim=512, depth=12, num_heads=8), 1024, 90, 2),

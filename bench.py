@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
+    ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=1)
     return ap.parse_args()
@@ -160,6 +161,11 @@ def main():
             rows.append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2))
         rows.sort(reverse=True)
         tot, key, flops, avg_ms, per_step = rows[0]
+        if args.gemm_table:
+            with open(args.gemm_table, "w") as f:
+                f.write("ms/step  avg_us  n/step  TFLOP/s  dtype,aL,bL,gather,M,N,K,batch,...\n")
+                for t_, k_, fl_, av_, n_ in rows:
+                    f.write(f"{t_ / 2:7.3f} {av_ * 1e3:8.1f} {n_:4d} {fl_ / (av_ * 1e-3) / 1e12:8.1f}  {k_}\n")
         achieved = flops / (avg_ms * 1e-3) / 1e12
         names = {0: "plain", 1: "conv-fwd", 2: "conv-dgrad", 3: "conv-wgrad"}
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",

@@ -442,7 +442,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.bias = d->bias; p.preact = (char*)d->preact; p.residual = (const char*)d->residual; p.colstats = d->colstats;
   p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
-  p.wo_shift = p.howo_shift = -1;
+  p.wo_shift = p.howo_shift = p.wq_shift = p.hwq_shift = -1;
   p.relu_src = (const char*)d->relu_src;
   for (int t = 0; t < 2; ++t) {
     p.bnb_x[t] = (const char*)d->bnb_x[t];

@@ -43,6 +43,7 @@ struct KParams {
   // strided conv-dgrad by input-pixel parity class: rows are the pixels (hi % sh == cls_h, wi % sw == cls_w),
   // K runs over the class's valid taps only (tapsel); cls_h < 0: all pixels, all taps
   int cls_h, cls_w, Hq, Wq, ntapsel;
+  int wq_shift, hwq_shift;   // log2(Wq), log2(Hq*Wq) when both are powers of two, else -1 (epilogue row decode)
   unsigned char tapsel[12];
   // fused backward-of-ReLU and BatchNorm-backward column sums in the bf16 staged epilogue (conv dgrad outputs)
   const char* relu_src;

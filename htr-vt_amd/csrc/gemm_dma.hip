@@ -87,6 +87,14 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.howo_shift = b;
     }
   }
+  p.wq_shift = p.hwq_shift = -1;
+  if (d->cls_h >= 0) {
+    const int a = ilog2_exact(p.Wq), b = ilog2_exact(p.Hq * p.Wq);
+    if (a >= 0 && b >= 0) {
+      p.wq_shift = a;
+      p.hwq_shift = b;
+    }
+  }
   const bool spec = use_loader_waves(d);
   if (bn == 256) return gemm_dma_dispatch_bn256(d, p, zdim, st, false);
   if (bn == 64) return gemm_dma_dispatch_bn64(d, p, zdim, st, spec);
@@ -95,3 +103,4 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
 }
 
 }  // namespace htrvt
+

@@ -9,3 +9,9 @@ int gemm_dma_dispatch_bn192(const HtrvtGemmDesc* d, const KParams& p, int zdim, 
   return dispatch<256, 192, 0>(d, p, zdim, st);
 }
 }  // namespace htrvt
+
+#ifdef HTRVT_EXP_STAMP
+extern "C" int htrvt_debug_read_bn192(void* dst, int nbytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(htrvt_dbg), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

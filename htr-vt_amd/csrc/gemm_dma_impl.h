@@ -21,6 +21,17 @@ using namespace htrvt;
 
 namespace {
 
+#ifdef HTRVT_EXP_STAMP
+__device__ unsigned long long htrvt_dbg[16 * 8192];   // one per translation unit (experiment builds only)
+#define HTRVT_STAMP(slot)                                                                         \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) htrvt_dbg[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define HTRVT_STAMP(slot) do { } while (0)
+#endif
+
+
 constexpr int BK = 64;
 constexpr unsigned OOB = 0x80000000u;
 
@@ -276,7 +287,8 @@ __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w <
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
 // DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
-template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD>
+// CSTATS: compile the per-column sum / sum-of-squares path (conv-forward kernels only: BatchNorm batch statistics)
+template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS>
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
@@ -323,12 +335,22 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   if (pass > 0) __syncthreads();   // the previous pass has drained the staging image
   // ---- phase 1: registers -> LDS (column-major bf16); loader waves hold no accumulators ----
   if (active) {
+  float biasv[TNP];
+#pragma unroll
+  for (int jp = 0; jp < TNP; ++jp) biasv[jp] = 0.f;
+  if (p.bias != nullptr) {   // all loads of the pass in flight together (clamped index: no per-column branch)
+#pragma unroll
+    for (int jp = 0; jp < TNP; ++jp) {
+      const int n = n0 + (wn * TN + pass * TNP + jp) * 32 + cl;
+      const float b = p.bias[n < p.N ? n : 0];
+      biasv[jp] = n < p.N ? b : 0.f;
+    }
+  }
 #pragma unroll
   for (int jp = 0; jp < TNP; ++jp) {
     const int j = pass * TNP + jp;
     const int ccol = (wn * TNP + jp) * 32 + cl;          // column in the staging image
-    const int n = n0 + (wn * TN + j) * 32 + cl;
-    const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    const float bias = biasv[jp];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -338,8 +360,10 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a = acc[i][j][4 * g + r];  // rows >= M and cols >= N hold exact zeros (zero-filled operands)
-          cs1[j] += a;
-          cs2[j] += a * a;
+          if constexpr (CSTATS) {
+            cs1[j] += a;
+            cs2[j] += a * a;
+          }
           v[r] = a * p.alpha + bias;
         }
         uint2 o;
@@ -350,84 +374,107 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
     }
   }
   }
+  HTRVT_STAMP(4);
   __syncthreads();
+  HTRVT_STAMP(5);
   // ---- phase 2: LDS -> (act / residual) -> global, 16 B per lane, 4 lanes = 64 contiguous bytes of one row ----
   // Items are processed U at a time: all global loads of the U items (residual, ReLU source, BN inputs, saved
   // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
   // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
   constexpr int U = DGRAD ? 2 : 4;
   const bool has_res = p.residual != nullptr, has_relu = DGRAD && p.relu_src != nullptr, has_pre_in = !DGRAD && p.act == 2;
+  const bool has_pre_out = !has_pre_in && p.preact != nullptr;
+  const bool ew = has_res || has_relu || has_pre_in || p.act == 1 || bnb;   // any arithmetic on the staged values
+  const bool cls = p.cls_h >= 0;
+  // Item walk: `wave` is wave-uniform, so the item's row block / column group and everything derived from them
+  // live in SGPRs; a lane adds its constant part.  Offsets are 32-bit element counts (operands < 2 GiB).
+  const unsigned ldc = (unsigned)p.ldc;
+  bf16_t* const Cb = reinterpret_cast<bf16_t*>(p.C) + coff;
+  const bf16_t* const resb = reinterpret_cast<const bf16_t*>(p.residual) + coff;
+  const bf16_t* const relub = reinterpret_cast<const bf16_t*>(p.relu_src) + coff;
+  bf16_t* const preb = reinterpret_cast<bf16_t*>(p.preact) + coff;
+  const bf16_t* const bx0 = reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + coff;
+  const bf16_t* const bx1 = reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + coff;
+  const unsigned lane_lds = (lg * 8 + q) * CST + (4 * pp) * 2;
   for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
-    long long o[U];
+    unsigned o[U];
     bool ok[U];
     uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
+    if (id0 == wave) HTRVT_STAMP(9);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int id = id0 + u * NWAVES;
-      int rbk, cg;
-      if constexpr (FIXED_COLS) {
-        cg = wave % GROUPS;
-        rbk = (wave / GROUPS) + ((id - wave) / NWAVES) * RB_STEP;
-      } else {
-        rbk = id / GROUPS;
-        cg = id - rbk * GROUPS;
-      }
-      const int crow0 = rbk * 16, ccol0 = cg * 32 + lg * 8;
-      int m = m0 + crow0 + lr;
-      const int half = ccol0 / (TNP * 32);                 // which wave column (wn) staged this column
-      const int n = n0 + (half * TN + pass * TNP) * 32 + (ccol0 - half * TNP * 32);
-      ok[u] = id < ITEMS && m < p.M && n < p.N;
-      if (p.cls_h >= 0) {  // class row -> input-pixel row of the NHWC gradient
-        const int hw = p.Hq * p.Wq;
-        const int b = m / hw, r = m - b * hw;
-        const int hq = r / p.Wq, wq = r - hq * p.Wq;
+      const bool live = id < ITEMS;
+      const int idc = live ? id : wave;           // a tail item re-reads the wave's first item and stores nothing
+      const int rbk = idc / GROUPS, cg = idc - rbk * GROUPS;   // (FIXED_COLS: cg == wave % GROUPS for every item)
+      const int half = (cg * 32) / (TNP * 32);    // which wave column (wn) staged this column group
+      const int nb = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
+      int m = m0 + rbk * 16 + lr;
+      ok[u] = live && m < p.M && nb < p.N;
+      if (cls) {  // class row -> input-pixel row of the NHWC gradient
+        int b, hq, wq;
+        if (p.wq_shift >= 0) {
+          b = m >> p.hwq_shift;
+          const int r = m & ((1 << p.hwq_shift) - 1);
+          hq = r >> p.wq_shift;
+          wq = r & ((1 << p.wq_shift) - 1);
+        } else {
+          const int hw = p.Hq * p.Wq;
+          b = m / hw;
+          const int r = m - b * hw;
+          hq = r / p.Wq;
+          wq = r - hq * p.Wq;
+        }
         m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
       }
-      o[u] = ok[u] ? coff + (long long)m * p.ldc + n : coff;   // coff itself is a valid element of every operand
-      if (has_res) rres[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + o[u]);
-      if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.relu_src) + o[u]);
-      if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.preact) + o[u]);
-      if (bnb) rbx[0][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + o[u]);
-      if (bnb2) rbx[1][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + o[u]);
-      const int idc = id < ITEMS ? id : wave;  // clamp the LDS address of a tail item
-      int rbk2, cg2;
-      if constexpr (FIXED_COLS) {
-        cg2 = cg;
-        rbk2 = (wave / GROUPS) + ((idc - wave) / NWAVES) * RB_STEP;
-      } else {
-        rbk2 = idc / GROUPS;
-        cg2 = idc - rbk2 * GROUPS;
-      }
-      const char* a0 = smem + (cg2 * 32 + lg * 8 + q) * CST + (rbk2 * 16 + 4 * pp) * 2;
+      o[u] = ok[u] ? (unsigned)m * ldc + (unsigned)nb : 0u;   // element 0 is a valid address of every operand
+      if (has_res) rres[u] = *reinterpret_cast<const uint4*>(resb + o[u]);
+      if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(relub + o[u]);
+      if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(preb + o[u]);
+      if (bnb) rbx[0][u] = *reinterpret_cast<const uint4*>(bx0 + o[u]);
+      if (bnb2) rbx[1][u] = *reinterpret_cast<const uint4*>(bx1 + o[u]);
+      const char* a0 = smem + (cg * 32) * CST + rbk * 32 + lane_lds;
       const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
       const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
       raw[u] = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
+    }
+#ifdef HTRVT_EXP_STAMP
+    if (id0 == wave) HTRVT_STAMP(10);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (id0 == wave) HTRVT_STAMP(11);
+#endif
+    if (!ew) {   // workgroup-uniform: the staged bf16 values are the result
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          if (has_pre_out) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
+          *reinterpret_cast<uint4*>(Cb + o[u]) = raw[u];
+        }
+      }
+      if (id0 == wave) HTRVT_STAMP(12);
+      continue;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       float v[8] = {bf16lo(raw[u].x), bf16hi(raw[u].x), bf16lo(raw[u].y), bf16hi(raw[u].y),
                     bf16lo(raw[u].z), bf16hi(raw[u].z), bf16lo(raw[u].w), bf16hi(raw[u].w)};
-      bool touched = false;
       if (has_pre_in) {
         const uint4 pr = rpre[u];
         const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
                             bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
-        touched = true;
-      } else if (p.preact != nullptr) {
-        if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.preact) + o[u]) = raw[u];
+      } else if (has_pre_out) {
+        if (ok[u]) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
       }
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        touched = true;
       }
       if (has_res) {
         const uint4 rr = rres[u];
         v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
         v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
-        touched = true;
       }
       if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
         const uint4 rs = rrelu[u];
@@ -435,7 +482,6 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
                             bf16lo(rs.z), bf16hi(rs.z), bf16lo(rs.w), bf16hi(rs.w)};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-        touched = true;
       }
       if (bnb) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
 #pragma unroll
@@ -452,18 +498,16 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
           }
         }
       }
-      uint4 out = raw[u];
-      if (touched) {
-        out.x = pack_bf16x2(v[0], v[1]);
-        out.y = pack_bf16x2(v[2], v[3]);
-        out.z = pack_bf16x2(v[4], v[5]);
-        out.w = pack_bf16x2(v[6], v[7]);
-      }
-      if (ok[u]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + o[u]) = out;
+      uint4 out;
+      out.x = pack_bf16x2(v[0], v[1]);
+      out.y = pack_bf16x2(v[2], v[3]);
+      out.z = pack_bf16x2(v[4], v[5]);
+      out.w = pack_bf16x2(v[6], v[7]);
+      if (ok[u]) *reinterpret_cast<uint4*>(Cb + o[u]) = out;
     }
   }
   }  // pass
-  if (p.colstats != nullptr) {
+  if (CSTATS && p.colstats != nullptr) {
     float* red = reinterpret_cast<float*>(smem + BNS * CST);  // [NWM][BN][2], behind the staged tile
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -552,6 +596,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
   constexpr int STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  HTRVT_STAMP(0);
   const int ntiles = p.tiles_m * p.tiles_n;
   int id = blockIdx.x;
   int z = blockIdx.z;
@@ -612,8 +657,10 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
     la.issue(p, lds0, kbeg, kend, lw);
     lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, lw);
   }
+  HTRVT_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  HTRVT_STAMP(2);
 
   for (int kt = 0; kt < nkt; ++kt) {
     char* cur = smem + (kt & 1) * STAGE;
@@ -643,12 +690,23 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
     __builtin_amdgcn_s_barrier();
   }
 
+  HTRVT_STAMP(3);
   // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
   if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
+    epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2, GATHER == 1>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
   else
     gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
                                                smem, consumer);
+  HTRVT_STAMP(6);
+#ifdef HTRVT_EXP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HTRVT_STAMP(7);
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    htrvt_dbg[blockIdx.x * 16 + 8] = hw;
+  }
+#endif
 }
 
 template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>

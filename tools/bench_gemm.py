@@ -136,6 +136,27 @@ def main():
         nn("NN dgrad-fc1 32768x768x3072", 32768, 768, 3072)
         nn("NN dgrad-qkv 32768x768x2304", 32768, 768, 2304)
         tn("TN wgrad-fc1 3072x768xK32768", 3072, 768, 32768, 8)
+    if not args.only or "mlp" in args.only:
+        M, D, F = 32768, 768, 3072
+        bias = torch.rand(F, device=dev)
+        pre = torch.empty(M, F, dtype=dt, device=dev)
+        plain("fc1 fwd plain", M, F, D)
+        plain("fc1 fwd +bias", M, F, D, bias=bias)
+        plain("fc1 fwd +bias+gelu", M, F, D, bias=bias, act=1)
+        plain("fc1 fwd +bias+gelu+preact", M, F, D, bias=bias, act=1, preact=pre)
+        a, b = rnd(M, D), rnd(D, F)
+        c = torch.empty(M, F, dtype=dt, device=dev)
+        pre2 = rnd(M, F)
+        ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=F, K=D, lda=D, ldb=F, ldc=F, b_layout=ops.MNMAJOR), args.iters)
+        rows.append(("fc2 dgrad plain (NN)", ms, 2.0 * M * F * D))
+        ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=F, K=D, lda=D, ldb=F, ldc=F, b_layout=ops.MNMAJOR, act=2,
+                                     preact=pre2), args.iters)
+        rows.append(("fc2 dgrad * gelu'(preact)", ms, 2.0 * M * F * D))
+    if "ksweep" in args.only:
+        for K in (64, 128, 256, 512, 768, 1536, 3072, 6144):
+            plain(f"NT 32768x3072 K={K}", 32768, 3072, K)
+        for K in (64, 128, 256, 512, 768, 1536, 3072, 6144):
+            plain(f"NT 32768x768 K={K}", 32768, 768, K)
     if not args.only or "conv" in args.only:
         conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)

@@ -167,13 +167,17 @@ __global__ __launch_bounds__(NT) void softmax_bwd_rows_kernel(const T* __restric
 // ------------------------------------------------------------------ column sums: out[c] += sum_r x[r*ld + c]
 // optional row filter: rows whose keep[(r % keep_mod)] != 0 are skipped (masked-token gradient)
 template <typename T>
-__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long long rows, int cols, long long ld,
-                                                    float* __restrict__ out, const float* __restrict__ keep,
-                                                    int keep_mod) {
-  constexpr int CH = Vec16<T>::N;
-  __shared__ float red[4][64][CH];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int chunk = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, long long rows, int cols, long long ld,
+                                                      float* __restrict__ out, const float* __restrict__ keep,
+                                                      int keep_mod) {
+  // block = 32 column chunks (16 B each) x 32 row lanes; a half-wave reads 512 contiguous bytes of one row and every
+  // thread keeps 4 row loads in flight.  Few, fat blocks on purpose: the per-block float atomics on one output
+  // address serialise at ~0.2 us each, so the row splits are capped at 64 by the launcher.
+  constexpr int CH = Vec16<T>::N, RL = 32;
+  using Raw = decltype(Vec16<T>().raw);
+  __shared__ float red[RL][32][CH];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int chunk = blockIdx.x * 32 + cl;
   const int nchunk = cols / CH;
   const long long per = (rows + gridDim.y - 1) / gridDim.y;
   const long long r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
@@ -181,21 +185,34 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
 #pragma unroll
   for (int j = 0; j < CH; ++j) a[j] = 0.f;
   if (chunk < nchunk) {
-    for (long long r = r0 + rl; r < r1; r += 4) {
-      if (keep != nullptr && keep[r % keep_mod] != 0.f) continue;
-      Vec16<T> v;
-      v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + r * ld + (long long)chunk * CH);
+    const T* xc = x + (long long)chunk * CH;
+    for (long long r = r0 + rl; r < r1; r += 4 * RL) {
+      Vec16<T> v[4];
+      bool use[4];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) a[j] += v.get(j);
+      for (int u = 0; u < 4; ++u) {
+        const long long ru = r + RL * u;
+        use[u] = ru < r1 && (keep == nullptr || keep[(unsigned)ru % (unsigned)keep_mod] == 0.f);
+        v[u].raw = *reinterpret_cast<const Raw*>(xc + (use[u] ? ru : r0) * ld);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) a[j] += use[u] ? v[u].get(j) : 0.f;
     }
   }
 #pragma unroll
   for (int j = 0; j < CH; ++j) red[rl][cl][j] = a[j];
   __syncthreads();
-  if (rl == 0 && chunk < nchunk) {
+  // 32 chunks x CH columns = 32*CH outputs, one thread each
+  if ((int)threadIdx.x < 32 * CH) {
+    const int c = threadIdx.x / CH, j = threadIdx.x - c * CH;
+    if (blockIdx.x * 32 + c < nchunk) {
+      float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < CH; ++j)
-      atomicAdd(&out[chunk * CH + j], red[0][cl][j] + red[1][cl][j] + red[2][cl][j] + red[3][cl][j]);
+      for (int k = 0; k < RL; ++k) t += red[k][c][j];
+      atomicAdd(&out[(blockIdx.x * 32 + c) * CH + j], t);
+    }
   }
 }
 
@@ -528,29 +545,55 @@ __global__ __launch_bounds__(NT) void rowsum_f32_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ weight packing / unpacking, cast, AdamW
+// One block = 16 output channels x 32 input channels x all taps, staged through LDS so that the float32 source rows
+// (contiguous [ci][tap] runs) and both packed destinations ([co][tap][ci] and [ci][tap][co]) move as contiguous runs.
+constexpr int PK_CO = 16, PK_CI = 32, PK_MAXT = 9;
+
 template <typename T>
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgr, int Co,
-                                        int Ci, int taps, int cpi, int cpo) {
-  const long long total = (long long)Co * Ci * taps;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % taps);
-    const long long r = i / taps;
-    const int ci = (int)(r % Ci), co = (int)(r / Ci);
-    const T v = from_f32<T>(w[i]);
-    fwd[((long long)co * taps + t) * cpi + ci] = v;
-    if (dgr) dgr[((long long)ci * taps + t) * cpo + co] = v;
+__global__ __launch_bounds__(NT) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd,
+                                                              T* __restrict__ dgr, int Co, int Ci, int taps, int cpi,
+                                                              int cpo) {
+  __shared__ float tile[PK_CO][PK_CI * PK_MAXT + 1];
+  const int co0 = blockIdx.y * PK_CO, ci0 = blockIdx.x * PK_CI;
+  const int run = PK_CI * taps;
+  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
+    const int r = i / run, c = i - r * run;
+    float v = 0.f;
+    if (co0 + r < Co && ci0 + c / taps < Ci) v = w[((long long)(co0 + r) * Ci + ci0) * taps + c];
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
+    const int r = i / run, rem = i - r * run;
+    const int t = rem / PK_CI, ci = rem - t * PK_CI;
+    if (co0 + r < Co && ci0 + ci < Ci) fwd[((long long)(co0 + r) * taps + t) * cpi + ci0 + ci] = from_f32<T>(tile[r][ci * taps + t]);
+  }
+  if (dgr != nullptr) {
+    for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
+      const int ci = i / (taps * PK_CO), rem = i - ci * taps * PK_CO;
+      const int t = rem / PK_CO, r = rem - t * PK_CO;
+      if (co0 + r < Co && ci0 + ci < Ci) dgr[((long long)(ci0 + ci) * taps + t) * cpo + co0 + r] = from_f32<T>(tile[r][ci * taps + t]);
+    }
   }
 }
 
-// packed is the wgrad GEMM output [taps][cpi][Co]
-__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad, int Co, int Ci, int taps,
-                                         int cpi) {
-  const long long total = (long long)Co * Ci * taps;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % taps);
-    const long long r = i / taps;
-    const int ci = (int)(r % Ci), co = (int)(r / Ci);
-    grad[i] += packed[((long long)t * cpi + ci) * Co + co];
+// packed is the wgrad GEMM output [taps][cpi][Co]; grad [Co][Ci][taps] += its transpose (same tiling as the pack)
+__global__ __launch_bounds__(NT) void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad,
+                                                               int Co, int Ci, int taps, int cpi) {
+  __shared__ float tile[PK_CO][PK_CI * PK_MAXT + 1];
+  const int co0 = blockIdx.y * PK_CO, ci0 = blockIdx.x * PK_CI;
+  const int run = PK_CI * taps;
+  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
+    const int ci = i / (taps * PK_CO), rem = i - ci * taps * PK_CO;
+    const int t = rem / PK_CO, r = rem - t * PK_CO;
+    float v = 0.f;
+    if (co0 + r < Co && ci0 + ci < Ci) v = packed[((long long)t * cpi + ci0 + ci) * Co + co0 + r];
+    tile[r][ci * taps + t] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
+    const int r = i / run, c = i - r * run;
+    if (co0 + r < Co && ci0 + c / taps < Ci) grad[((long long)(co0 + r) * Ci + ci0) * taps + c] += tile[r][c];
   }
 }
 
@@ -639,11 +682,12 @@ extern "C" int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, f
                             int dtype, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(cols % ch == 0 && ld % ch == 0, "htrvt_colsum: cols/ld must be multiples of %d", ch);
-  long long splits = rows / 64;
+  const int gx = (cols / ch + 31) / 32;
+  long long splits = rows / 128;         // >= 128 rows (4 per thread) per block, at most 64 atomics per output
+  if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
-  if (splits > 128) splits = 128;
-  dim3 grid((cols / ch + 63) / 64, (unsigned)splits);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)x, (long long)rows,
+  dim3 grid(gx, (unsigned)splits);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)rows,
                                        cols, (long long)ld, out, keep, keep_mod > 0 ? keep_mod : 1));
   return check_launch("colsum");
 }
@@ -738,8 +782,8 @@ extern "C" int htrvt_conv1_wgrad(const float* img, const float* stats, const voi
 
 extern "C" int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
                                       int cpad_out, int dtype, void* stream) {
-  const long long total = (long long)Co * Ci * taps;
-  dim3 grid(grid_for(total));
+  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT, "pack_conv_weight: taps=%d unsupported (1..%d)", taps, PK_MAXT);
+  dim3 grid((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO);
   DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
                                        (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out));
   return check_launch("pack_conv_weight");
@@ -747,8 +791,8 @@ extern "C" int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, in
 
 extern "C" int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in,
                                        void* stream) {
-  const long long total = (long long)Co * Ci * taps;
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, packed, grad, Co, Ci,
+  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT, "unpack_conv_wgrad: taps=%d unsupported (1..%d)", taps, PK_MAXT);
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO), dim3(NT), 0, (hipStream_t)stream, packed, grad, Co, Ci,
                      taps, cpad_in);
   return check_launch("unpack_conv_wgrad");
 }

@@ -59,6 +59,26 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// GELU for results that are rounded to bfloat16 anyway: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, one
+// v_rcp + one v_exp + 5 FMAs instead of libm's branchy erff); the derivative reuses the same exponential,
+// exp(-z^2) with z = x / sqrt(2) being sqrt(2 pi) * pdf(x).
+__device__ __forceinline__ float erf_abs_as(float az, float& e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  e = __expf(-az * az);
+  const float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  return fmaf(-poly, e, 1.0f);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  float e;
+  const float er = copysignf(erf_abs_as(fabsf(x) * 0.70710678118654752440f, e), x);
+  return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  float e;
+  const float er = copysignf(erf_abs_as(fabsf(x) * 0.70710678118654752440f, e), x);
+  return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
+}
+
 // Epilogue of one wave's TM x TN block of 32x32 accumulator tiles.
 //   acc[i][j][r] is C(row = mrow0 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), col = ncol0 + 32 j + (lane&31))
 // NWM = number of waves stacked along M in the workgroup (for the BN column-sum reduction through LDS).

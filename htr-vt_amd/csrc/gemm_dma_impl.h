@@ -463,13 +463,13 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
         const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
                             bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_fast(x[e]);
       } else if (has_pre_out) {
         if (ok[u]) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
       }
       if (p.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
       }
       if (has_res) {
         const uint4 rr = rres[u];

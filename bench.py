@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
+    ap.add_argument("--sam", action="store_true", help="the reference's full iteration (train.py:119-128): SAM(AdamW) = two "
+                    "fwd+bwd passes + climb/restore + AdamW + ModelEma update; images/s counts each image once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
@@ -118,8 +120,21 @@ def main():
         tr.engine.fuse_bn_backward = not args.no_fuse_bn
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
 
-        def one_step():
-            return tr.step(x, tg, tl, keep_mask=keep)
+        if args.sam:
+            from htrvt_amd.ema import ModelEma
+            ema = ModelEma(model, 0.9999)
+            torch.manual_seed(8)
+            keep2 = model.generate_span_mask(N, 0.4, 8)
+            it = [0]
+
+            def one_step():
+                l_ = tr.sam_step(x, tg, tl, keep_mask=keep, keep_mask2=keep2)
+                ema.update(model, num_updates=it[0] / 2)
+                it[0] += 1
+                return l_
+        else:
+            def one_step():
+                return tr.step(x, tg, tl, keep_mask=keep)
 
     def barrier():
         if use_dist:
@@ -181,6 +196,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": ("HTR-VT base eval forward + CTC loss" if args.forward_only else
+                                        "HTR-VT base (d768/4L/6h, nb_cls 80) reference iteration: SAM(AdamW) 2x(fwd + CTC + bwd) + EMA"
+                                        if args.sam else
                                         "HTR-VT base (d768/4L/6h, nb_cls 80) training step: fwd + fused CTC + bwd + AdamW"
                                         + (" + RCCL grad all-reduce" if world > 1 else "")),
                           "image": f"1x64x{args.width}", "batch_per_gpu": B, "global_batch": B * world,

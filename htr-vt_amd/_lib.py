@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 KMAJOR, MNMAJOR = 0, 1
 GATHER_NONE, GATHER_CONV_FWD, GATHER_CONV_DGRAD, GATHER_CONV_WGRAD = 0, 1, 2, 3
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 
 class GemmDesc(C.Structure):
@@ -74,6 +74,12 @@ PROTOTYPES = {
     "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "htrvt_sumsq_blocks": (i32, [i64]),
+    "htrvt_sumsq": (i32, [vp, i64, vp, vp, vp]),
+    "htrvt_sam_first_step": (i32, [vp, vp, vp, i64, f32, vp, vp]),
+    "htrvt_sam_restore": (i32, [vp, vp, i64, vp]),
+    "htrvt_ema_update": (i32, [vp, i32, i64, f64, vp]),
+    "htrvt_ctc_greedy_decode": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp]),
     "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
     "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),

@@ -51,3 +51,20 @@ class _CTCMean(torch.autograd.Function):
 def ctc_loss(logits, targets, target_lengths):
     """mean over the batch of the per-sample CTC negative log-likelihood (not length-normalised)."""
     return _CTCMean.apply(logits, targets, target_lengths)
+
+
+def greedy_decode(logits, ncharacter=None):
+    """valid.py:40-42 + CTCLabelConverter.decode (utils/utils.py:72-86) on the device: per frame arg-max of the
+    logits (= arg-max of their log-softmax), blanks / repeats / indices >= ncharacter dropped.
+    logits [B,T,C] float32 -> (idx [B,T] int32 left-packed, lens [B] int32); ncharacter = len(converter.character)."""
+    from ._lib import check, lib
+    from .ops import ptr, stream
+    if not logits.is_cuda:
+        raise RuntimeError("htrvt_amd.greedy_decode needs a device tensor on an MI355X (no CPU fallback)")
+    logits = logits.float().contiguous()
+    B, T, Cc = logits.shape
+    out = torch.zeros(B, T, dtype=torch.int32, device=logits.device)
+    lens = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.htrvt_ctc_greedy_decode(ptr(logits), B, T, Cc, Cc, int(Cc if ncharacter is None else ncharacter), ptr(out),
+                                      ptr(lens), stream()), "ctc_greedy_decode")
+    return out, lens

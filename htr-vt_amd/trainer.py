@@ -120,3 +120,26 @@ class Trainer:
         loss = self.forward_backward(img, targets, lengths, keep_mask)
         self.optimizer_step(lr)
         return loss
+
+    def sam_step(self, img, targets, lengths, keep_mask=None, keep_mask2=None, lr=None, rho=0.05):
+        """One iteration of the reference's optimizer, SAM(AdamW) (train.py:119-126, utils/sam.py:15-38, adaptive=False):
+        gradients at w -> climb to w + rho g/|g| -> gradients there (a second, independently masked pass) -> back to w
+        -> AdamW with the second gradients.  Three flat launches around the two forward/backward passes; under data
+        parallelism both passes all-reduce, so every rank computes the same norm.  Returns the first-pass loss."""
+        from ._lib import check, lib
+        from .ops import ptr, stream
+        fl = self.flat
+        n = fl.flat_p.numel()
+        if not hasattr(self, "_sam_buf"):
+            self._sam_buf = (torch.empty_like(fl.flat_p), torch.empty(lib.htrvt_sumsq_blocks(n), device=fl.flat_p.device),
+                             torch.empty(1, device=fl.flat_p.device))
+        old_p, partial, norm_sq = self._sam_buf
+        loss = self.forward_backward(img, targets, lengths, keep_mask)
+        check(lib.htrvt_sumsq(ptr(fl.flat_g), n, ptr(partial), ptr(norm_sq), stream()), "sumsq")
+        check(lib.htrvt_sam_first_step(ptr(fl.flat_p), ptr(fl.flat_g), ptr(old_p), n, float(rho), ptr(norm_sq), stream()),
+              "sam_first_step")
+        self.engine.weights_epoch += 1
+        self.forward_backward(img, targets, lengths, keep_mask2)
+        check(lib.htrvt_sam_restore(ptr(fl.flat_p), ptr(old_p), n, stream()), "sam_restore")
+        self.optimizer_step(lr)
+        return loss

@@ -196,6 +196,31 @@ int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stre
 int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, void* stream);
 
+/* ---- around the path: SAM, EMA, greedy decode ---------------- */
+/* out[0] = sum x^2 (deterministic two-stage); partial: htrvt_sumsq_blocks(n) floats of scratch.  With x = the flat
+ * gradient buffer this is SAM._grad_norm()^2 (utils/sam.py:47-56). */
+int htrvt_sumsq_blocks(int64_t n);
+int htrvt_sumsq(const float* x, int64_t n, float* partial, float* out, void* stream);
+/* SAM.first_step (utils/sam.py:15-27, adaptive=False): old_p = p; p += g * rho / (sqrt(norm_sq[0]) + 1e-12) */
+int htrvt_sam_first_step(float* p, const float* g, float* old_p, int64_t n, float rho, const float* norm_sq, void* stream);
+/* SAM.second_step's restore (utils/sam.py:31-34): p = old_p; htrvt_adamw then applies the base optimizer */
+int htrvt_sam_restore(float* p, const float* old_p, int64_t n, void* stream);
+/* ModelEma.update (utils/utils.py:158-173) over every state_dict entry in one launch: ema = ema*decay + (1-decay)*model
+ * in float32 (int64 entries: float math, truncated on the way back).  table: device array of `count` entries. */
+typedef struct HtrvtEmaEntry {
+  void* ema;
+  const void* model;
+  int64_t numel;
+  int32_t is_int64;
+  int32_t pad_;
+} HtrvtEmaEntry;
+int htrvt_ema_update(const HtrvtEmaEntry* table, int count, int64_t max_numel, double decay, void* stream);
+/* valid.py:40-42 + CTCLabelConverter.decode (utils/utils.py:72-86): out[b, 0:out_len[b]] = arg-max class per frame with
+ * blanks (0), repeats and indices >= ncharacter removed.  logits [B,T,ld>=C] float32 (arg-max of the logits = arg-max of
+ * their log-softmax), out [B,T] int32. */
+int htrvt_ctc_greedy_decode(const float* logits, int B, int T, int C, int64_t ld, int ncharacter, int32_t* out,
+                            int32_t* out_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -419,3 +419,55 @@ def synthetic_batch(B, H, W, nb_cls, N, seed=0):
     lengths = rng.integers(lo, hi, size=B).astype(np.int32)
     targets = rng.integers(1, nb_cls, size=int(lengths.sum())).astype(np.int32)
     return x, targets, lengths
+
+
+# ----------------------------------------------------------------------------
+# The training iteration around the path: SAM(AdamW) + EMA
+# ----------------------------------------------------------------------------
+def adamw_update(p, g, m, v, step, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.5):
+    """torch.optim.AdamW single-tensor step (train.py:94 hyper-parameters), in place on float32 tensors."""
+    b1, b2 = betas
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def sam_adamw_iteration(sd, cfg: Config, x, targets, target_lengths, keep1, keep2, opt_state, lr, rho=0.05,
+                        weight_decay=0.5):
+    """One reference iteration (train.py:119-126 with utils/sam.py:15-38, adaptive=False) on a state_dict, in place:
+    gradients at w -> w + rho g / (|g| + 1e-12) -> gradients there -> restore w -> AdamW with the second gradients.
+    opt_state: {'step': int, 'm': {name: tensor}, 'v': {...}} (created empty on first use).
+    BatchNorm running statistics advance twice, exactly as two train-mode forwards do.  Returns the first-pass loss."""
+    def grads_at(keep):
+        loss, _, grads, stats = loss_and_grads(sd, cfg, x, targets, target_lengths, keep, train=True)
+        for k, (mean, var_unb) in stats.items():            # running-stat update of a train-mode forward
+            sd[k + ".running_mean"].mul_(0.9).add_(mean, alpha=0.1)
+            sd[k + ".running_var"].mul_(0.9).add_(var_unb, alpha=0.1)
+            sd[k + ".num_batches_tracked"] += 1
+        return loss, grads
+
+    loss, g1 = grads_at(keep1)
+    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in g1.values())).float()
+    scale = rho / (norm + 1e-12)
+    old = {k: sd[k].clone() for k in g1}
+    for k, g in g1.items():
+        sd[k].add_(g * scale)
+    _, g2 = grads_at(keep2)
+    opt_state.setdefault("step", 0)
+    opt_state["step"] += 1
+    for k, g in g2.items():
+        sd[k].copy_(old[k])
+        m = opt_state.setdefault("m", {}).setdefault(k, torch.zeros_like(g))
+        v = opt_state.setdefault("v", {}).setdefault(k, torch.zeros_like(g))
+        adamw_update(sd[k], g, m, v, opt_state["step"], lr, weight_decay=weight_decay)
+    return loss
+
+
+def ema_update(ema_sd, model_sd, num_updates, decay=0.9999):
+    """utils/utils.py:158-173: every state_dict entry, int64 counters included (float math, truncating copy_)."""
+    d = min(decay, (1 + num_updates) / (10 + num_updates)) if num_updates >= 0 else decay
+    for k, e in ema_sd.items():
+        e.copy_(e * d + (1.0 - d) * model_sd[k])

@@ -15,6 +15,8 @@
 //                      (two 128-B rows share a 256-B bank line: the 16 rows of a ds_read_b128 lane group hit 16 slots)
 //   MN-major operand : [64 k][rows*2 B], chunk c stored at (c + 4*(k&3)) mod CPR  -> ds_read_b64_tr_b16 (transpose)
 #pragma once
+#include <type_traits>
+
 #include "gemm_common.h"
 
 using namespace htrvt;
@@ -382,9 +384,9 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
   // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
   constexpr int U = DGRAD ? 2 : 4;
-  const bool has_res = p.residual != nullptr, has_relu = DGRAD && p.relu_src != nullptr, has_pre_in = !DGRAD && p.act == 2;
-  const bool has_pre_out = !has_pre_in && p.preact != nullptr;
-  const bool ew = has_res || has_relu || has_pre_in || p.act == 1 || bnb;   // any arithmetic on the staged values
+  const bool rt_res = p.residual != nullptr, rt_relu = DGRAD && p.relu_src != nullptr, rt_pre_in = !DGRAD && p.act == 2;
+  const bool rt_pre_out = !rt_pre_in && p.preact != nullptr, rt_gelu = p.act == 1;
+  const int rt_nb = bnb2 ? 2 : (bnb ? 1 : 0);
   const bool cls = p.cls_h >= 0;
   // Item walk: `wave` is wave-uniform, so the item's row block / column group and everything derived from them
   // live in SGPRs; a lane adds its constant part.  Offsets are 32-bit element counts (operands < 2 GiB).
@@ -396,115 +398,142 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   const bf16_t* const bx0 = reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + coff;
   const bf16_t* const bx1 = reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + coff;
   const unsigned lane_lds = (lg * 8 + q) * CST + (4 * pp) * 2;
-  for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
-    unsigned o[U];
-    bool ok[U];
-    uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
-    if (id0 == wave) HTRVT_STAMP(9);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int id = id0 + u * NWAVES;
-      const bool live = id < ITEMS;
-      const int idc = live ? id : wave;           // a tail item re-reads the wave's first item and stores nothing
-      const int rbk = idc / GROUPS, cg = idc - rbk * GROUPS;   // (FIXED_COLS: cg == wave % GROUPS for every item)
-      const int half = (cg * 32) / (TNP * 32);    // which wave column (wn) staged this column group
-      const int nb = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
-      int m = m0 + rbk * 16 + lr;
-      ok[u] = live && m < p.M && nb < p.N;
-      if (cls) {  // class row -> input-pixel row of the NHWC gradient
-        int b, hq, wq;
-        if (p.wq_shift >= 0) {
-          b = m >> p.hwq_shift;
-          const int r = m & ((1 << p.hwq_shift) - 1);
-          hq = r >> p.wq_shift;
-          wq = r & ((1 << p.wq_shift) - 1);
-        } else {
-          const int hw = p.Hq * p.Wq;
-          b = m / hw;
-          const int r = m - b * hw;
-          hq = r / p.Wq;
-          wq = r - hq * p.Wq;
-        }
-        m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
-      }
-      o[u] = ok[u] ? (unsigned)m * ldc + (unsigned)nb : 0u;   // element 0 is a valid address of every operand
-      if (has_res) rres[u] = *reinterpret_cast<const uint4*>(resb + o[u]);
-      if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(relub + o[u]);
-      if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(preb + o[u]);
-      if (bnb) rbx[0][u] = *reinterpret_cast<const uint4*>(bx0 + o[u]);
-      if (bnb2) rbx[1][u] = *reinterpret_cast<const uint4*>(bx1 + o[u]);
-      const char* a0 = smem + (cg * 32) * CST + rbk * 32 + lane_lds;
-      const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
-      const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
-      raw[u] = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
-    }
-#ifdef HTRVT_EXP_STAMP
-    if (id0 == wave) HTRVT_STAMP(10);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (id0 == wave) HTRVT_STAMP(11);
-#endif
-    if (!ew) {   // workgroup-uniform: the staged bf16 values are the result
+
+  // The walk itself, with each epilogue feature either compiled in (1), compiled out (0) or decided at run time (2).
+  // The hot combinations are instantiated with constants: their side loads then sit in straight-line code and are all
+  // in flight together (behind run-time branches hipcc puts an `s_waitcnt vmcnt(0)` in front of every one of them,
+  // i.e. one full memory round trip per load and item).
+  auto walk = [&](auto f_res, auto f_relu, auto f_pre_in, auto f_pre_out, auto f_gelu, auto f_nb) {
+    constexpr int FRES = decltype(f_res)::value, FRELU = decltype(f_relu)::value, FPIN = decltype(f_pre_in)::value;
+    constexpr int FPOUT = decltype(f_pre_out)::value, FGELU = decltype(f_gelu)::value, FNB = decltype(f_nb)::value;
+    const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
+    const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
+    const bool has_pre_in = FPIN == 1 || (FPIN == 2 && rt_pre_in);
+    const bool has_pre_out = FPOUT == 1 || (FPOUT == 2 && rt_pre_out);
+    const bool has_gelu = FGELU == 1 || (FGELU == 2 && rt_gelu);
+    const int nb = FNB == 3 ? rt_nb : FNB;
+    const bool ew = has_res || has_relu || has_pre_in || has_gelu || nb > 0;   // any arithmetic on the staged values
+    for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
+      unsigned o[U];
+      bool ok[U];
+      uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          if (has_pre_out) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
-          *reinterpret_cast<uint4*>(Cb + o[u]) = raw[u];
+        const int id = id0 + u * NWAVES;
+        const bool live = id < ITEMS;
+        const int idc = live ? id : wave;           // a tail item re-reads the wave's first item and stores nothing
+        const int rbk = idc / GROUPS, cg = idc - rbk * GROUPS;   // (FIXED_COLS: cg == wave % GROUPS for every item)
+        const int half = (cg * 32) / (TNP * 32);    // which wave column (wn) staged this column group
+        const int nbc = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
+        int m = m0 + rbk * 16 + lr;
+        ok[u] = live && m < p.M && nbc < p.N;
+        if (cls) {  // class row -> input-pixel row of the NHWC gradient
+          int b, hq, wq;
+          if (p.wq_shift >= 0) {
+            b = m >> p.hwq_shift;
+            const int r = m & ((1 << p.hwq_shift) - 1);
+            hq = r >> p.wq_shift;
+            wq = r & ((1 << p.wq_shift) - 1);
+          } else {
+            const int hw = p.Hq * p.Wq;
+            b = m / hw;
+            const int r = m - b * hw;
+            hq = r / p.Wq;
+            wq = r - hq * p.Wq;
+          }
+          m = (b * p.Hi + hq * p.sh + p.cls_h) * p.Wi + wq * p.sw + p.cls_w;
         }
+        o[u] = ok[u] ? (unsigned)m * ldc + (unsigned)nbc : 0u;   // element 0 is a valid address of every operand
+        if (has_res) rres[u] = *reinterpret_cast<const uint4*>(resb + o[u]);
+        if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(relub + o[u]);
+        if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(preb + o[u]);
+        if (nb > 0) rbx[0][u] = *reinterpret_cast<const uint4*>(bx0 + o[u]);
+        if (nb > 1) rbx[1][u] = *reinterpret_cast<const uint4*>(bx1 + o[u]);
+        const char* a0 = smem + (cg * 32) * CST + rbk * 32 + lane_lds;
+        const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+        const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * CST));
+        raw[u] = __builtin_bit_cast(uint4, s16x8_t{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w});
       }
-      if (id0 == wave) HTRVT_STAMP(12);
-      continue;
-    }
+      if (!ew) {   // workgroup-uniform: the staged bf16 values are the result
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float v[8] = {bf16lo(raw[u].x), bf16hi(raw[u].x), bf16lo(raw[u].y), bf16hi(raw[u].y),
-                    bf16lo(raw[u].z), bf16hi(raw[u].z), bf16lo(raw[u].w), bf16hi(raw[u].w)};
-      if (has_pre_in) {
-        const uint4 pr = rpre[u];
-        const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
-                            bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_fast(x[e]);
-      } else if (has_pre_out) {
-        if (ok[u]) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
-      }
-      if (has_res) {
-        const uint4 rr = rres[u];
-        v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
-        v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
-      }
-      if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
-        const uint4 rs = rrelu[u];
-        const float y[8] = {bf16lo(rs.x), bf16hi(rs.x), bf16lo(rs.y), bf16hi(rs.y),
-                            bf16lo(rs.z), bf16hi(rs.z), bf16lo(rs.w), bf16hi(rs.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-      }
-      if (bnb) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          if (t == 1 && !bnb2) break;
-          const uint4 xr = rbx[t][u];
-          const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
-                              bf16lo(xr.z), bf16hi(xr.z), bf16lo(xr.w), bf16hi(xr.w)};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float gv = ok[u] ? v[e] : 0.f;
-            bs1[t][e] += gv;
-            bs2[t][e] += gv * ((x[e] - bmu[t][e]) * brs[t][e]);
+        for (int u = 0; u < U; ++u) {
+          if (ok[u]) {
+            if (has_pre_out) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
+            *reinterpret_cast<uint4*>(Cb + o[u]) = raw[u];
           }
         }
+        continue;
       }
-      uint4 out;
-      out.x = pack_bf16x2(v[0], v[1]);
-      out.y = pack_bf16x2(v[2], v[3]);
-      out.z = pack_bf16x2(v[4], v[5]);
-      out.w = pack_bf16x2(v[6], v[7]);
-      if (ok[u]) *reinterpret_cast<uint4*>(Cb + o[u]) = out;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[8] = {bf16lo(raw[u].x), bf16hi(raw[u].x), bf16lo(raw[u].y), bf16hi(raw[u].y),
+                      bf16lo(raw[u].z), bf16hi(raw[u].z), bf16lo(raw[u].w), bf16hi(raw[u].w)};
+        if (has_pre_in) {
+          const uint4 pr = rpre[u];
+          const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
+                              bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_fast(x[e]);
+        } else if (has_pre_out) {
+          if (ok[u]) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
+        }
+        if (has_gelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+        }
+        if (has_res) {
+          const uint4 rr = rres[u];
+          v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
+          v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
+        }
+        if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
+          const uint4 rs = rrelu[u];
+          const float y[8] = {bf16lo(rs.x), bf16hi(rs.x), bf16lo(rs.y), bf16hi(rs.y),
+                              bf16lo(rs.z), bf16hi(rs.z), bf16lo(rs.w), bf16hi(rs.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+        }
+        if (nb > 0) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t >= nb) break;
+            const uint4 xr = rbx[t][u];
+            const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
+                                bf16lo(xr.z), bf16hi(xr.z), bf16lo(xr.w), bf16hi(xr.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gv = ok[u] ? v[e] : 0.f;
+              bs1[t][e] += gv;
+              bs2[t][e] += gv * ((x[e] - bmu[t][e]) * brs[t][e]);
+            }
+          }
+        }
+        uint4 out;
+        out.x = pack_bf16x2(v[0], v[1]);
+        out.y = pack_bf16x2(v[2], v[3]);
+        out.z = pack_bf16x2(v[4], v[5]);
+        out.w = pack_bf16x2(v[6], v[7]);
+        if (ok[u]) *reinterpret_cast<uint4*>(Cb + o[u]) = out;
+      }
     }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  if constexpr (DGRAD) {   // conv dgrad: [residual] [ReLU mask + 1 or 2 BatchNorm-backward sum sets]
+    if (!rt_res && !rt_relu && rt_nb == 0) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (rt_res && !rt_relu && rt_nb == 0) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (!rt_res && rt_relu && rt_nb == 1) walk(I0{}, I1{}, I0{}, I0{}, I0{}, I1{});
+    else if (rt_res && rt_relu && rt_nb == 1) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I1{});
+    else if (rt_res && rt_relu && rt_nb == 2) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I2{});
+    else walk(I2{}, I2{}, I0{}, I0{}, I0{}, I3{});
+  } else {                 // linear / conv forward / attention: [residual] | GELU [+ saved pre-activation] | * GELU'
+    if (!rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (!rt_res && rt_gelu && rt_pre_out) walk(I0{}, I0{}, I0{}, I1{}, I1{}, I0{});
+    else if (!rt_res && rt_pre_in) walk(I0{}, I0{}, I1{}, I0{}, I0{}, I0{});
+    else walk(I2{}, I0{}, I2{}, I2{}, I2{}, I0{});
   }
   }  // pass
   if (CSTATS && p.colstats != nullptr) {
@@ -692,9 +721,12 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
 
   HTRVT_STAMP(3);
   // uniform choice: bf16 C with 16-byte-aligned rows -> staged, vectorised epilogue; float32 C -> direct
-  if (!p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0))
-    epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2, GATHER == 1>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
-  else
+  // (256-column tiles serve the float32 split-K weight gradients; their bf16 output, explicit tile selector only,
+  //  takes the direct epilogue: the staged one would not leave the loaders' descriptors their SGPRs)
+  if (BN <= 192 && !p.c_f32 && ((p.ldc | p.N | coff) & 7) == 0 && ((reinterpret_cast<unsigned long long>(p.C) & 15) == 0)) {
+    if constexpr (BN <= 192)
+      epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2, GATHER == 1>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
+  } else
     gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
                                                smem, consumer);
   HTRVT_STAMP(6);

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const float* __restrict__
 __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, float count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, float momentum, float* running_mean, float* running_var,
-                                                         float* scale, float* shift, float* save_mean, float* save_rstd) {
+                                                         long long* num_batches_tracked, float* scale, float* shift,
+                                                         float* save_mean, float* save_rstd) {
   __shared__ double red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (rl != 0 || c >= C) return;
   s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
   s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
@@ -376,8 +378,9 @@ extern "C" int htrvt_conv1_fwd(const float* img, const float* stats, const float
 }
 
 extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
-                                 float* shift, float* save_mean, float* save_rstd, void* stream) {
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                                 float* save_rstd, void* stream) {
   // caller guarantees 64 scratch rows after `rows` rows of `partial` when rows > 256
   const float* src = partial;
   int r = rows;
@@ -389,7 +392,7 @@ extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float co
     r = 64;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(NT), 0, (hipStream_t)stream, src, r, C, count, gamma,
-                     beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+                     beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_rstd);
   return check_launch("bn_finalize");
 }
 

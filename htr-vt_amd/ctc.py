@@ -21,12 +21,18 @@ def _prep_targets(targets, target_lengths, device):
     return tg.to(device), tl.to(device), off.to(device), maxlen
 
 
-def ctc_forward_backward(logits, targets, target_lengths, want_grad=True, grad_scale=1.0):
+def stage_targets(targets, target_lengths, device):
+    """upload the label arrays (three small host->device copies).  Call it BEFORE enqueueing the forward: a copy from
+    pageable memory waits for everything already on the stream, i.e. it would stall the host for a whole forward."""
+    return _prep_targets(targets, target_lengths, device)
+
+
+def ctc_forward_backward(logits, targets, target_lengths, want_grad=True, grad_scale=1.0, staged=None):
     """logits [B,T,C] float32 (device).  Returns (nll [B], dmean/dlogits [B,T,C] or None)."""
     assert logits.is_cuda and logits.dtype == torch.float32
     logits = logits.contiguous()
     B, T, C = logits.shape
-    tg, tl, off, maxlen = _prep_targets(targets, target_lengths, logits.device)
+    tg, tl, off, maxlen = staged if staged is not None else _prep_targets(targets, target_lengths, logits.device)
     nll = torch.empty(B, dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits) if want_grad else None
     ws = torch.empty(lib.htrvt_ctc_workspace_floats(B, T, maxlen), dtype=torch.float32, device=logits.device)

@@ -75,13 +75,38 @@ class Engine:
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
         self._side, self._side_active = None, False
         self.saved = None
+        self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
 
     # ------------------------------------------------------------------ small helpers
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.dev)
 
     def _zeros(self, *shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        """float32 zeros for atomically accumulated outputs.  Inside backward() they are slices of ONE arena cleared by
+        one memset per step (31 fill launches otherwise, each with its ~5 us dispatch gap)."""
+        if dtype is not torch.float32 or self._zoff is None:
+            return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64
+        self._zneed += n_al
+        if self._zarena is None or self._zoff + n_al > self._zarena.numel():
+            return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        t = self._zarena[self._zoff:self._zoff + n].view(*shape)
+        self._zoff += n_al
+        return t
+
+    def _zarena_begin(self):
+        if self._zarena is None or self._zarena.numel() < self._zneed_max:
+            self._zarena = torch.zeros(max(self._zneed_max, 1), dtype=torch.float32, device=self.dev) if self._zneed_max else None
+        elif self._zarena is not None:
+            self._zarena.zero_()
+        self._zoff, self._zneed = 0, 0
+
+    def _zarena_end(self):
+        self._zneed_max = max(self._zneed_max, self._zneed)
+        self._zoff = None
 
     def _wkey(self, t):
         return (t.data_ptr(), t._version, self.weights_epoch)
@@ -266,9 +291,8 @@ class Engine:
             mean, rstd = self._empty(C, dtype=torch.float32), self._empty(C, dtype=torch.float32)
             check(lib.htrvt_bn_finalize(ptr(cs), rows, C, float(count), ptr(P[prefix + ".weight"]), ptr(P[prefix + ".bias"]),
                                         BN_EPS, BN_MOMENTUM, ptr(P[prefix + ".running_mean"]),
-                                        ptr(P[prefix + ".running_var"]), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
-                                        stream()), "bn_finalize")
-            P[prefix + ".num_batches_tracked"].add_(1)
+                                        ptr(P[prefix + ".running_var"]), ptr(P[prefix + ".num_batches_tracked"]),
+                                        ptr(scale), ptr(shift), ptr(mean), ptr(rstd), stream()), "bn_finalize")
             return scale, shift, mean, rstd
         check(lib.htrvt_bn_eval_coeffs(ptr(P[prefix + ".weight"]), ptr(P[prefix + ".bias"]), ptr(P[prefix + ".running_mean"]),
                                        ptr(P[prefix + ".running_var"]), BN_EPS, ptr(scale), ptr(shift), C, stream()),
@@ -330,8 +354,11 @@ class Engine:
         dx = torch.empty_like(x)
         check(lib.htrvt_layernorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(partial),
                                       rows, D, self.dti, stream()), "layernorm_bwd")
-        check(lib.htrvt_colsum(ptr(partial), nblk, D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
-        check(lib.htrvt_colsum(partial.data_ptr() + 4 * D, nblk, D, 2 * D, ptr(dbeta), None, 1, 0, stream()), "colsum")
+        if dbeta.data_ptr() == dgamma.data_ptr() + 4 * D:   # weight and bias adjacent in the flat gradient buffer: one launch
+            check(lib.htrvt_colsum(ptr(partial), nblk, 2 * D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
+        else:
+            check(lib.htrvt_colsum(ptr(partial), nblk, D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
+            check(lib.htrvt_colsum(partial.data_ptr() + 4 * D, nblk, D, 2 * D, ptr(dbeta), None, 1, 0, stream()), "colsum")
         return dx
 
     # ------------------------------------------------------------------ forward
@@ -346,6 +373,9 @@ class Engine:
         st = stream()
         sv = {} if save else None
         C1 = s.D // 4
+        keep = None
+        if keep_mask is not None:   # uploaded before anything is enqueued: a pageable host->device copy waits for the stream
+            keep = keep_mask.to(device=self.dev, dtype=torch.float32).contiguous()
 
         # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
         stats = self._empty(B, 2, dtype=torch.float32)
@@ -401,9 +431,6 @@ class Engine:
         assert N == s.num_patches, f"token count {N} != num_patches {s.num_patches}"
         D = s.D
         tok = self._empty(B, N, D)
-        keep = None
-        if keep_mask is not None:
-            keep = keep_mask.to(device=self.dev, dtype=torch.float32).contiguous()
         pos = P["pos_embed"].reshape(N, D)
         check(lib.htrvt_pool_tokens(ptr(x), ptr(keep), ptr(P["mask_token"]), ptr(pos), ptr(tok), B, Hc, N, D, self.dti, st),
               "pool_tokens")
@@ -470,6 +497,7 @@ class Engine:
         h, hd = s.heads, s.hd
         scale = hd ** -0.5
         dy = dy.contiguous()
+        self._zarena_begin()
         assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
         self._side_active = self.overlap_wgrad
 
@@ -639,4 +667,5 @@ class Engine:
                                         B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
         self._join_side()
         self._side_active = False
+        self._zarena_end()
         self.saved = None

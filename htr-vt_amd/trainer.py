@@ -96,11 +96,12 @@ class Trainer:
     def forward_backward(self, img, targets, lengths, keep_mask=None):
         """forward + CTC + backward on this rank's shard; the (already averaged) gradients land in the flat
         gradient buffer.  Returns the local mean loss (device scalar)."""
-        from .ctc import ctc_forward_backward
+        from .ctc import ctc_forward_backward, stage_targets
         eng, fl = self.engine, self.flat
+        staged = stage_targets(targets, lengths, img.device)   # before the forward is enqueued (see stage_targets)
         fl.flat_g.zero_()
         y = eng.forward(self.P, img, keep_mask=keep_mask, train=True, save=True)
-        nll, dy = ctc_forward_backward(y, targets, lengths, want_grad=True, grad_scale=1.0 / self.world)
+        nll, dy = ctc_forward_backward(y, targets, lengths, want_grad=True, grad_scale=1.0 / self.world, staged=staged)
         eng.backward(self.P, fl.G, dy, after_encoder=fl.reduce_encoder_bucket)
         fl.reduce_stem_bucket()
         return nll.mean()

@@ -100,9 +100,9 @@ int htrvt_conv1_fwd(const float* img, const float* stats, const float* w, void* 
                     int B, int H, int W, int C, int dtype, void* stream);
 /* BN statistics from partial sums: train mode.  partial [rows][2][C]; count = #elements per channel.
  * Writes scale = gamma*rstd, shift = beta - mean*scale, saves mean/rstd, updates running stats
- * (momentum, unbiased running_var) when running_mean != NULL. */
+ * (momentum, unbiased running_var) when running_mean != NULL and adds 1 to *num_batches_tracked (int64, may be NULL). */
 int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,
-                      float eps, float momentum, float* running_mean, float* running_var,
+                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 /* eval mode: scale/shift from running stats */
 int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

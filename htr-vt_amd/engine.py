@@ -484,7 +484,7 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P, G, dy, after_encoder=None):
+    def backward(self, P, G, dy, after_encoder=None, after_layer3=None):
         """dy: float32 [B,N,C] = dLoss/dlogits.  Accumulates dLoss/dparam into G (dict name -> float32 tensor,
         same shapes as P; the caller zeroes it).  Uses the activations saved by forward(save=True)."""
         sv = self.saved
@@ -595,6 +595,9 @@ class Engine:
             blk = blocks[bi]
             p = blk["p"]
             C = blk["cb"].shape[-1]
+            if bi == len(blocks) - 3 and after_layer3 is not None:   # both layer-3 blocks (78 % of the stem's weights) are done
+                self._join_side()
+                after_layer3()
             if parts is None:   # dout is an unmasked gradient: classic path (mask + sums in one reduction pass)
                 dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3],
                                            want_g=True)

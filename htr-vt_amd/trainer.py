@@ -6,10 +6,12 @@ without the SAM second pass (SURVEY.md 8(f-1) lists SAM as a later row).
 
 MI355X-first layout: every trainable parameter is a view into ONE flat float32
 buffer (same for gradients and the two Adam moments), so the optimizer is one
-kernel launch and the gradient exchange is two large all-reduces (xGMI is
+kernel launch and the gradient exchange is three large all-reduces (xGMI is
 point-to-point: few, large messages).  The encoder/head bucket -- the tail of
-the flat buffer, complete early in backward -- is reduced on a side stream while
-the stem backward (~80 % of the FLOPs) still runs; the stem bucket follows.
+the flat buffer, complete early in backward -- and then the layer-3 bucket (78 %
+of the stem's weights, complete two blocks later) are reduced on a side stream
+while the rest of the stem backward still runs; only the last 22 MB (conv1,
+layer1, layer2) are exchanged after the backward.
 The data-parallel average is folded into the loss gradient (CTC grad_scale =
 1/world_size), so the all-reduce is a plain SUM and nothing rescales afterwards.
 """
@@ -34,7 +36,7 @@ class FlatParams:
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.G = {}
-        off, self.enc_start = 0, None
+        off, self.enc_start, self.l3_start = 0, None, None
         for n, p in named:
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
@@ -42,9 +44,13 @@ class FlatParams:
             self.G[n] = self.flat_g[off:off + k].view_as(p)
             if self.enc_start is None and n.startswith("blocks."):
                 self.enc_start = off        # blocks.*, norm.*, head.* follow in state_dict order
+            if self.l3_start is None and n.startswith("patch_embed.layer3."):
+                self.l3_start = off         # layer3.* is the tail of the stem segment: 19.5 M of its 25 M weights
             off += (k + 3) // 4 * 4
         if self.enc_start is None:
             self.enc_start = 0
+        if self.l3_start is None or self.l3_start > self.enc_start:
+            self.l3_start = self.enc_start
         self.side = torch.cuda.Stream(device=dev) if (self.coll and dev.type == "cuda") else None
         if self.coll:   # identical replicas: rank 0's parameters and BN buffers
             dist.broadcast(self.flat_p, 0)
@@ -69,10 +75,23 @@ class FlatParams:
         with torch.cuda.stream(self.side):
             dist.all_reduce(self.flat_g[self.enc_start:])
 
+    def reduce_layer3_bucket(self):
+        """all-reduce(SUM) of the patch_embed.layer3.* gradients, complete after the first two stem blocks of the
+        backward; on CUDA on the side stream behind the encoder bucket, under the layer-2/1 backward."""
+        if not self.coll or self.l3_start == self.enc_start:
+            return
+        if self.side is None:
+            dist.all_reduce(self.flat_g[self.l3_start:self.enc_start])
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(self.flat_g[self.l3_start:self.enc_start])
+
     def reduce_stem_bucket(self):
+        """the rest of the stem (conv1, layer1, layer2: 5.5 M weights), after the backward"""
         if not self.coll:
             return
-        dist.all_reduce(self.flat_g[:self.enc_start])
+        dist.all_reduce(self.flat_g[:self.l3_start])
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
@@ -102,7 +121,7 @@ class Trainer:
         fl.flat_g.zero_()
         y = eng.forward(self.P, img, keep_mask=keep_mask, train=True, save=True)
         nll, dy = ctc_forward_backward(y, targets, lengths, want_grad=True, grad_scale=1.0 / self.world, staged=staged)
-        eng.backward(self.P, fl.G, dy, after_encoder=fl.reduce_encoder_bucket)
+        eng.backward(self.P, fl.G, dy, after_encoder=fl.reduce_encoder_bucket, after_layer3=fl.reduce_layer3_bucket)
         fl.reduce_stem_bucket()
         return nll.mean()
 

@@ -109,6 +109,7 @@ def _dp_worker(rank, world, port, out):
             g.copy_((rank + 1) / world * torch.ones_like(g))
         fp.flat_g.mul_(g0)
         fp.reduce_encoder_bucket()
+        fp.reduce_layer3_bucket()
         fp.reduce_stem_bucket()
         want = sum((r + 1) / world for r in range(world)) * g0
         pad_free = torch.zeros_like(want, dtype=torch.bool)
@@ -120,6 +121,9 @@ def _dp_worker(rank, world, port, out):
         first_enc = names.index("blocks.0.norm1.weight")
         enc_ok = all(n.startswith(("blocks.", "norm.", "head.")) for n in names[first_enc:]) and \
             not any(n.startswith(("blocks.", "norm.", "head.")) for n in names[:first_enc])
+        l3_names = [n for n in names if n.startswith("patch_embed.layer3.")]
+        l3_off = (fp.G[l3_names[0]].data_ptr() - fp.flat_g.data_ptr()) // 4
+        enc_ok = enc_ok and 0 < fp.l3_start == l3_off < fp.enc_start and names.index(l3_names[-1]) == first_enc - 1
         out[rank] = (same_params, ok, enc_ok, int(fp.enc_start))
     finally:
         dist.destroy_process_group()

@@ -613,7 +613,11 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
 // SPEC = 0: every wave issues its share of the DMA, then multiplies (NTH = 2*BM).
 // SPEC = 1: wave specialisation -- 4 extra loader waves own ALL address arithmetic + DMA issue of the next k-tile
 //           while the BM/32 consumer waves run nothing but ds_read + MFMA; one workgroup barrier per k-tile.
-template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
+// NSTAGE = 3 (tiles of at most 128 columns: 3 x 48 KB of LDS): the DMA of k-tile t+2 is issued before k-tile t+1 has
+// landed, so two k-tiles are in flight while one is multiplied.  With two stages the next DMA cannot start before
+// the barrier that follows the previous one's arrival, and the loop is bound by one DMA round trip per k-tile
+// (measured with the MFMAs removed: 2 400-3 300 cycles per k-tile against 1 900 for the MFMA side alone).
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>
 __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KParams p) {
   using T = bf16_t;
   constexpr int NWC = BM / 32;                 // consumer (MFMA) waves
@@ -682,23 +686,46 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const unsigned lds0 = lds_addr_of(smem);
   constexpr bool KMAP = (GATHER == 1 || GATHER == 2);
-  if (nkt > 0 && loader) {
-    la.issue(p, lds0, kbeg, kend, lw);
-    lb.template issue<KMAP>(p, lds0 + A_BYTES, kbeg, kend, lw);
+  // every DMA-issuing wave issues exactly PER_TILE pieces per k-tile, so "all but the youngest tile have landed" is
+  // s_waitcnt vmcnt(PER_TILE) for it (consumer-only waves have nothing outstanding)
+  constexpr int PER_TILE = DmaLoader<BM, AL, GATHER, NWL>::NP + DmaLoader<BN, BL, 0, NWL>::NP;
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "two or three LDS stages");
+  static_assert(PER_TILE <= 63, "vmcnt immediate");
+  if (loader) {
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t) {
+      if (t < nkt) {
+        la.issue(p, lds0 + t * STAGE, kbeg + t * BK, kend, lw);
+        lb.template issue<KMAP>(p, lds0 + t * STAGE + A_BYTES, kbeg + t * BK, kend, lw);
+      }
+    }
   }
   HTRVT_STAMP(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NSTAGE == 3 && nkt > 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   HTRVT_STAMP(2);
 
+  int s_cur = 0, s_nxt = NSTAGE - 1;   // stage being multiplied / stage the DMA issued in this iteration fills
   for (int kt = 0; kt < nkt; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    const unsigned nxt = lds0 + ((kt + 1) & 1) * STAGE;
-    if (loader && kt + 1 < nkt) {  // DMA of the next k-tile flies during this tile's MFMAs
-      la.issue(p, nxt, kbeg + (kt + 1) * BK, kend, lw);
-      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + (kt + 1) * BK, kend, lw);
+    char* cur = smem + s_cur * STAGE;
+    const unsigned nxt = lds0 + s_nxt * STAGE;
+    const int kt_issue = kt + NSTAGE - 1;
+#ifdef HTRVT_EXP_NODMA
+    if (false) {
+#else
+    if (loader && kt_issue < nkt) {  // this DMA flies during the MFMAs of this and (three stages) the next k-tile
+#endif
+      la.issue(p, nxt, kbeg + kt_issue * BK, kend, lw);
+      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + kt_issue * BK, kend, lw);
     }
+#ifdef HTRVT_EXP_NOMMA
+    if (false) {
+#else
     if (consumer) {
+#endif
       const char* sa = cur;
       const char* sb = cur + A_BYTES;
 #pragma unroll
@@ -715,8 +742,14 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // k-tile kt+1 must have landed before the barrier; with three stages the tile issued above may stay in flight
+    if (NSTAGE == 3 && kt_issue < nkt)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    s_cur = (s_cur + 1 == NSTAGE) ? 0 : s_cur + 1;
+    s_nxt = (s_nxt + 1 == NSTAGE) ? 0 : s_nxt + 1;
   }
 
   HTRVT_STAMP(3);
@@ -741,12 +774,13 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
 #endif
 }
 
-template <int BM, int BN, int AL, int BL, int GATHER, int SPEC>
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>
 int launch(const KParams& p, int zdim, hipStream_t st) {
   constexpr int NTH = BM * 2 + SPEC * 256;
-  constexpr int smem = 2 * (Geo<BM>::BYTES + Geo<BN>::BYTES);
+  constexpr int smem = NSTAGE * (Geo<BM>::BYTES + Geo<BN>::BYTES);
+  static_assert(smem <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER, SPEC>;
+  auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER, SPEC, NSTAGE>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -762,15 +796,15 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
   return rc ? rc : 1;
 }
 
-template <int BM, int BN, int SPEC>
+template <int BM, int BN, int SPEC, int NSTAGE = 2>
 int dispatch(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st) {
   const int al = d->a_layout, bl = d->b_layout, g = d->gather;
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2, SPEC>(p, zdim, st);
-  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, SPEC>(p, zdim, st);
-  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, SPEC>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 0) return launch<BM, BN, 0, 0, 0, SPEC, NSTAGE>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 1) return launch<BM, BN, 0, 0, 1, SPEC, NSTAGE>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_KMAJOR && g == 2) return launch<BM, BN, 0, 0, 2, SPEC, NSTAGE>(p, zdim, st);
+  if (al == HTRVT_KMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 0, 1, 0, SPEC, NSTAGE>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 0) return launch<BM, BN, 1, 1, 0, SPEC, NSTAGE>(p, zdim, st);
+  if (al == HTRVT_MNMAJOR && bl == HTRVT_MNMAJOR && g == 3) return launch<BM, BN, 1, 1, 3, SPEC, NSTAGE>(p, zdim, st);
   return 0;
 }
 

@@ -152,6 +152,13 @@ def main():
         ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=F, K=D, lda=D, ldb=F, ldc=F, b_layout=ops.MNMAJOR, act=2,
                                      preact=pre2), args.iters)
         rows.append(("fc2 dgrad * gelu'(preact)", ms, 2.0 * M * F * D))
+    if "ldpad" in args.only:
+        for (M, N, K) in ((32768, 3072, 768), (32768, 768, 3072), (32768, 3072, 3072), (32768, 2304, 768), (32768, 768, 768)):
+            for pad in (0, 64, 32, 8):
+                a, b = rnd(M, K + pad), rnd(N, K + pad)
+                c = torch.empty(M, N + pad, dtype=dt, device=dev)
+                ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=N, K=K, lda=K + pad, ldb=K + pad, ldc=N + pad), args.iters)
+                rows.append((f"NT {M}x{N}x{K} ld pad {pad}", ms, 2.0 * M * N * K))
     if "ksweep" in args.only:
         for K in (64, 128, 256, 512, 768, 1536, 3072, 6144):
             plain(f"NT 32768x3072 K={K}", 32768, 3072, K)

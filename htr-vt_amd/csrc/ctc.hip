@@ -28,6 +28,13 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   if (m == -INFINITY) return -INFINITY;
   return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
+// the same on the hardware exp2 / log2 units (1 ulp each; the arguments that matter are within a few units of 0):
+// this sits on the serial chain of 2 T steps
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == -INFINITY) return -INFINITY;
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
 
 __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
                                                  const int* __restrict__ tgt_len, const int* __restrict__ tgt_off,
@@ -71,6 +78,30 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
     A[s] = a;
   }
   __syncthreads();
+  if (S <= NT) {
+    // one state per thread: its label, its skip rule and -- one step ahead, so that no step waits for memory -- its
+    // emission x[t][label] live in registers; a step is three LDS reads, one log-sum-exp, one barrier
+    const bool act = tid < S;
+    const int e = act ? ext[tid] : 0;
+    const bool skip = act && tid >= 2 && e != 0 && e != ext[tid - 2];
+    float xn = (act && T > 1) ? x[(long long)C + e] : 0.f;
+    for (int t = 1; t < T; ++t) {
+      const float xc = xn;
+      if (act && t + 1 < T) xn = x[(long long)(t + 1) * C + e];
+      if (act) {
+        const float a0 = prev[tid];
+        const float a1 = tid >= 1 ? prev[tid - 1] : -INFINITY;
+        const float a2 = skip ? prev[tid - 2] : -INFINITY;
+        const float a = lse3_fast(a0, a1, a2) + (xc - lse[t]);
+        cur[tid] = a;
+        A[(long long)t * Smax + tid] = a;
+      }
+      __syncthreads();
+      float* tmp = prev;
+      prev = cur;
+      cur = tmp;
+    }
+  } else {
   for (int t = 1; t < T; ++t) {
     const float* xt = x + (long long)t * C;
     const float l = lse[t];
@@ -88,6 +119,7 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
     prev = cur;
     cur = tmp;
   }
+  }
   if (tid == 0) s_ll = lse2(prev[S - 1], S > 1 ? prev[S - 2] : -INFINITY);
   __syncthreads();
   const float ll = s_ll;
@@ -102,6 +134,60 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
 
   // ---- beta sweep + gradient ----
   // prev/cur are reused for beta; all reads of the alpha buffers are behind the barrier above
+  if (S <= NT) {
+    const bool act = tid < S;
+    const int e = act ? ext[tid] : 0;
+    const bool skip = act && tid + 2 < S && ext[tid + 2] != 0 && ext[tid + 2] != e;
+    float xn = act ? x[(long long)(T - 1) * C + e] : 0.f;          // emission and alpha of the step about to run
+    float an = act ? A[(long long)(T - 1) * Smax + tid] : 0.f;
+    float gn = tid < C ? x[(long long)(T - 1) * C + tid] : 0.f;    // logit of class `tid` for the gradient row
+    for (int t = T - 1; t >= 0; --t) {
+      const float* xt = x + (long long)t * C;
+      const float l = lse[t];
+      float* occ = (t & 1) ? occ1 : occ0;
+      const float xc = xn, ac = an, gc = gn;
+      if (t > 0) {
+        if (act) {
+          xn = x[(long long)(t - 1) * C + e];
+          an = A[(long long)(t - 1) * Smax + tid];
+        }
+        if (tid < C) gn = x[(long long)(t - 1) * C + tid];
+      }
+      if (act) {
+        float bt;
+        if (t == T - 1) {
+          bt = (tid >= S - 2) ? (xc - l) : -INFINITY;
+        } else {
+          const float b0 = prev[tid];
+          const float b1 = tid + 1 < S ? prev[tid + 1] : -INFINITY;
+          const float b2 = skip ? prev[tid + 2] : -INFINITY;
+          bt = lse3_fast(b0, b1, b2) + (xc - l);
+        }
+        cur[tid] = bt;
+      }
+      // occupancy exp(alpha + beta - emission - ll): the blank states (every even s, half of all) would serialise on
+      // one LDS address, so each wave sums them first
+      float ob = 0.f;
+      if (act) {
+        const float ab = ac + cur[tid];
+        const float o = ab != -INFINITY ? __expf(ab - (xc - l) - ll) : 0.f;
+        if (e == 0) ob = o;
+        else if (o != 0.f) atomicAdd(&occ[e], o);
+      }
+      ob = wave_sum(ob);
+      if (lane == 0 && ob != 0.f) atomicAdd(&occ[0], ob);
+      __syncthreads();
+      for (int c = tid; c < C; c += NT) {
+        const float xv = c == tid ? gc : xt[c];
+        g[(long long)t * C + c] = (expf(xv - l) - occ[c]) * invB;
+        occ[c] = 0.f;
+      }
+      float* tmp = prev;
+      prev = cur;
+      cur = tmp;
+    }
+    return;
+  }
   for (int t = T - 1; t >= 0; --t) {
     const float* xt = x + (long long)t * C;
     const float l = lse[t];

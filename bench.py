@@ -46,6 +46,19 @@ def parse():
     return ap.parse_args()
 
 
+def synthetic_batch(B, H, W, nb_cls, N, seed=0):
+    """SURVEY.md 8(d) synthetic inputs: uniform [0,1) images, CTC-feasible random targets (lengths 20 .. min(90, N/2))"""
+    import numpy as np
+    g = torch.Generator().manual_seed(1234 + seed)
+    x = torch.rand(B, 1, H, W, generator=g)
+    rng = np.random.default_rng(seed)
+    hi = max(3, min(90, N // 2))
+    lo = min(20, hi - 1)
+    lengths = rng.integers(lo, hi, size=B).astype(np.int32)
+    targets = rng.integers(1, nb_cls, size=int(lengths.sum())).astype(np.int32)
+    return x, targets, lengths
+
+
 def cpu_baseline(args, mask):
     """oracle (CPU port of the reference path) on a bounded sample of the same workload"""
     from oracle import htrvt_oracle as O
@@ -57,7 +70,7 @@ def cpu_baseline(args, mask):
     torch.set_num_threads(cores)
     cfg = O.Config(80, (64, args.width), embed_dim=768, depth=4, num_heads=6)
     sd = O.init_state_dict(cfg, seed=123)
-    x, tg, tl = O.synthetic_batch(args.cpu_batch, 64, args.width, 80, cfg.num_patches, seed=0)
+    x, tg, tl = synthetic_batch(args.cpu_batch, 64, args.width, 80, cfg.num_patches, seed=0)
     times = []
     for it in range(args.cpu_iters + 1):
         t0 = time.perf_counter()
@@ -93,14 +106,13 @@ def main():
     from htrvt_amd.ctc import ctc_forward_backward
     from htrvt_amd.model import HTR_VT
     from htrvt_amd.trainer import Trainer
-    from oracle import htrvt_oracle as O          # only for synthetic_batch + cpu_baseline (checker / baseline leg)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(123)                                                  # option.py default --seed 123
     model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=dtype).to(dev)
     N = model.num_patches
     B = args.batch
-    x, tg, tl = O.synthetic_batch(B, 64, args.width, 80, N, seed=rank)
+    x, tg, tl = synthetic_batch(B, 64, args.width, 80, N, seed=rank)
     x = x.to(dev)
     torch.manual_seed(7)
     keep = model.generate_span_mask(N, 0.4, 8)                              # run/iam.sh: --mask-ratio 0.4 --max-span-length 8

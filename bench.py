@@ -188,15 +188,25 @@ def main():
             rows.append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2))
         rows.sort(reverse=True)
         tot, key, flops, avg_ms, per_step = rows[0]
+        names = {0: "plain", 1: "conv-fwd", 2: "conv-dgrad", 3: "conv-wgrad"}
         if args.gemm_table:
             with open(args.gemm_table, "w") as f:
                 f.write("ms/step  avg_us  n/step  TFLOP/s  dtype,aL,bL,gather,M,N,K,batch,...\n")
                 for t_, k_, fl_, av_, n_ in rows:
                     f.write(f"{t_ / 2:7.3f} {av_ * 1e3:8.1f} {n_:4d} {fl_ / (av_ * 1e-3) / 1e12:8.1f}  {k_}\n")
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        names = {0: "plain", 1: "conv-fwd", 2: "conv-dgrad", 3: "conv-wgrad"}
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected), if this is that kernel
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+                for ent in json.load(f)["kernels"]:
+                    k_ = ent["key"]
+                    if (args.dtype, names[key[3]], key[4], key[5], key[6]) == (k_["dtype"], k_["gather"], k_["M"], k_["N"], k_["K"]) \
+                            and B == 128 and args.width == 1024:
+                        traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r01_pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"gemm_kernel<{args.dtype},{names[key[3]]},a{key[1]}b{key[2]}> M={key[4]} N={key[5]} K={key[6]} batch={key[7]}",
                 "launches_per_step": per_step, "avg_ms": round(avg_ms, 4),
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 1),

@@ -257,3 +257,36 @@ def test_other_baseline_configs_step(tag, kw, W, nb, B, dtype):
     loss.backward()
     assert torch.isfinite(loss).item()
     assert all(torch.isfinite(p.grad).all().item() for p in m.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_odd_batch_and_non_power_of_two_width(dtype):
+    """W = 576 (9 patches of 64), B = 3: the pixel decodes of the conv gathers, the parity-class dgrad row mapping and
+    the weight-gradient loaders take their division paths (no shift shortcuts), tiles have M / N tails everywhere"""
+    import htrvt_amd
+    cfg = O.Config(80, (64, 576), embed_dim=256, depth=2, num_heads=4)
+    sd = O.init_state_dict(cfg, seed=13, randomize_affine=True)
+    x, targets, lengths = O.synthetic_batch(3, 64, 576, 80, cfg.num_patches, seed=6)
+    torch.manual_seed(21)
+    keep = O.span_mask(cfg.num_patches, 0.4, 8)
+    m = _model(cfg, sd, dtype=dtype).train()
+    y = m(x.cuda(), keep_mask=keep)
+    loss = htrvt_amd.ctc_loss(y, targets, lengths)
+    loss.backward()
+    ref_loss, ref_logits, ref_grads, _ = O.loss_and_grads(sd, cfg, x, targets, lengths, keep, dtype=torch.float64)
+    err = (y.detach().cpu().double() - ref_logits).abs().max().item()
+    print(dtype, "train-mode logits max-abs vs float64 oracle", err, "loss", float(loss), ref_loss)
+    assert err < (LOGIT_TOL if dtype == torch.float32 else 0.3)
+    assert abs(float(loss) - ref_loss) < (1e-4 if dtype == torch.float32 else 3e-2) * abs(ref_loss)
+    worst = 1.0
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = p.grad.double().flatten().cpu(), ref_grads[n].double().flatten()
+        if n.endswith("attn.qkv.bias"):            # the key third has an identically zero gradient
+            D = a.numel() // 3
+            a, b = torch.cat([a[:D], a[2 * D:]]), torch.cat([b[:D], b[2 * D:]])
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > (0.999 if dtype == torch.float32 else 0.8), (n, cos)
+    print(dtype, "worst gradient cosine vs float64 oracle", worst)

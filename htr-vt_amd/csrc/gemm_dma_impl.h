@@ -383,7 +383,6 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   // Items are processed U at a time: all global loads of the U items (residual, ReLU source, BN inputs, saved
   // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
   // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
-  constexpr int U = DGRAD ? 2 : 4;
   const bool rt_res = p.residual != nullptr, rt_relu = DGRAD && p.relu_src != nullptr, rt_pre_in = !DGRAD && p.act == 2;
   const bool rt_pre_out = !rt_pre_in && p.preact != nullptr, rt_gelu = p.act == 1;
   const int rt_nb = bnb2 ? 2 : (bnb ? 1 : 0);
@@ -406,6 +405,8 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   auto walk = [&](auto f_res, auto f_relu, auto f_pre_in, auto f_pre_out, auto f_gelu, auto f_nb) {
     constexpr int FRES = decltype(f_res)::value, FRELU = decltype(f_relu)::value, FPIN = decltype(f_pre_in)::value;
     constexpr int FPOUT = decltype(f_pre_out)::value, FGELU = decltype(f_gelu)::value, FNB = decltype(f_nb)::value;
+    // items in flight per wave: 4, or 2 where two BatchNorm sum sets (64 accumulators) leave no registers for more
+    constexpr int U = (DGRAD && FNB >= 2) ? 2 : 4;
     const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
     const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
     const bool has_pre_in = FPIN == 1 || (FPIN == 2 && rt_pre_in);

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("kh", i32), ("kw", i32), ("sh", i32), ("sw", i32), ("ph", i32), ("pw", i32), ("Cpad", i32),
         ("cls_h", i32), ("cls_w", i32),
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
-        ("bias", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
+        ("bias", vp), ("colscale", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
         ("relu_src", vp), ("bnb_x", vp * 2), ("bnb_mean", vp * 2), ("bnb_rstd", vp * 2), ("bnb_partial", vp * 2),
         ("bnb_tile0", i32),
         ("A", vp), ("B", vp), ("C", vp),

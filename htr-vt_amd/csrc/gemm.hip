@@ -439,7 +439,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.kh = d->kh; p.kw = d->kw; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw; p.Cpad = d->Cpad;
   p.alpha = d->alpha;
   p.act = d->act; p.c_f32 = d->c_f32 || d->dtype == HTRVT_F32; p.accumulate = d->accumulate;
-  p.bias = d->bias; p.preact = (char*)d->preact; p.residual = (const char*)d->residual; p.colstats = d->colstats;
+  p.bias = d->bias; p.colscale = d->colscale; p.preact = (char*)d->preact; p.residual = (const char*)d->residual; p.colstats = d->colstats;
   p.tiles_m = (d->M + bm - 1) / bm;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = p.wq_shift = p.hwq_shift = -1;

@@ -35,6 +35,7 @@ struct KParams {
   float alpha;
   int act, c_f32, accumulate;
   const float* bias;
+  const float* colscale;     // per-column multiplier (eval-mode BatchNorm scale) or NULL
   char* preact;
   const char* residual;
   float* colstats;
@@ -82,7 +83,9 @@ __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
 // Epilogue of one wave's TM x TN block of 32x32 accumulator tiles.
 //   acc[i][j][r] is C(row = mrow0 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), col = ncol0 + 32 j + (lane&31))
 // NWM = number of waves stacked along M in the workgroup (for the BN column-sum reduction through LDS).
-template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS>
+// EXTRAS: compile the per-column scale and the trailing ReLU (eval-mode BatchNorm folded into a convolution); the
+// 256-column LDS-DMA kernels (float32 split-K weight gradients) leave them out: they have no SGPRs to spare
+template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS, bool EXTRAS = true>
 __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KParams& p, char* Cb, long long coff, int mrow0,
                                               int ncol0, int wm, int n0, int tile_m, int lane, char* smem,
                                               bool active = true) {
@@ -104,10 +107,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
       for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32 + cl;
         const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+        const float al = (EXTRAS && p.colscale != nullptr) ? p.alpha * p.colscale[n] : p.alpha;
         float* col = Cf + (long long)(mrow0 + i * 32 + 4 * h) * p.ldc + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r] * p.alpha + bias;
+          const float v = acc[i][j][r] * al + bias;
           float* dst = col + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc;
           if (p.accumulate)
             atomicAdd(dst, v);
@@ -126,6 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
       const int n = ncol0 + j * 32 + cl;
       const bool nok = n < p.N;
       const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+      const float al = (EXTRAS && p.colscale != nullptr && nok) ? p.alpha * p.colscale[n] : p.alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -133,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
           const float a = acc[i][j][r];
           cs1[j] += a;
           cs2[j] += a * a;
-          float v = a * p.alpha + bias;
+          float v = a * al + bias;
           const long long o = coff + (long long)m * p.ldc + n;
           if (p.act == 2) {  // backward of GELU: multiply by gelu'(saved pre-activation)
             const float xp = p.c_f32 ? reinterpret_cast<const float*>(p.preact)[o]
@@ -148,12 +153,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KPa
           if (p.act == 1) v = gelu_erf(v);
           if (p.c_f32) {
             if (p.residual != nullptr) v += reinterpret_cast<const float*>(p.residual)[o];
+            if (EXTRAS && p.act == 3) v = fmaxf(v, 0.f);
             if (p.accumulate)
               atomicAdd(reinterpret_cast<float*>(Cb) + o, v);
             else
               reinterpret_cast<float*>(Cb)[o] = v;
           } else {
             if (p.residual != nullptr) v += to_f32(reinterpret_cast<const T*>(p.residual)[o]);
+            if (EXTRAS && p.act == 3) v = fmaxf(v, 0.f);
             reinterpret_cast<T*>(Cb)[o] = from_f32<T>(v);
           }
         }

@@ -32,7 +32,7 @@ int pick_bn(const HtrvtGemmDesc* d) {
   // (256x384 would save 29 % but its 192 accumulator registers per wave do not fit beside the loader state)
   // measured (tools/bench_gemm.py --tiles 3 4 6): +8 % on the N=768 conv wgrad, +20 % on 4096^3, but -20 % where the
   // tile count stops filling whole rounds of 256 CUs (N=768 / 2304 Linear layers) -> conv wgrad and explicit only
-  if (N % 256 == 0 && !fused && (d->tile == 6 || (d->tile == 0 && d->gather == HTRVT_GATHER_CONV_WGRAD))) return 256;
+  if (N % 256 == 0 && !fused && d->colscale == nullptr && d->act != 3 && (d->tile == 6 || (d->tile == 0 && d->gather == HTRVT_GATHER_CONV_WGRAD))) return 256;
   if (N <= 64) return 64;
   if (N <= 128 || d->tile == 7 || d->tile == 8) return 128;   // 7 / 8: experiment selectors, 128-column tiles with 2 / 3 stages
   const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;
@@ -76,6 +76,11 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
   if (d->relu_src != nullptr || d->bnb_partial[0] != nullptr) {
     // served only by the staged epilogue with a fixed column group per wave (12 waves, 6/4/2 column groups)
     if (!use_loader_waves(d) || d->c_f32 || (d->ldc & 7) || (d->N & 7)) return 0;
+  }
+  if (d->colscale != nullptr || d->act == 3) {
+    // per-column scale / trailing ReLU exist in the staged bf16 epilogue of the conv-forward kernels only
+    if (d->gather != HTRVT_GATHER_CONV_FWD || d->c_f32 || (d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;
+    if (d->batch > 1 && ((d->sC_o | d->sC_i) & 7)) return 0;
   }
   const int bn = pick_bn(d);
   p.tiles_m = (d->M + BM_ - 1) / BM_;

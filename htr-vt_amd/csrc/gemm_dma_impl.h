@@ -290,7 +290,7 @@ __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w &
 
 // DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
 // CSTATS: compile the per-column sum / sum-of-squares path (conv-forward kernels only: BatchNorm batch statistics)
-template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS>
+template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS>   // CSTATS (conv forward) also enables colscale / ReLU-last
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
@@ -337,9 +337,12 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   if (pass > 0) __syncthreads();   // the previous pass has drained the staging image
   // ---- phase 1: registers -> LDS (column-major bf16); loader waves hold no accumulators ----
   if (active) {
-  float biasv[TNP];
+  float biasv[TNP], scalev[TNP];
 #pragma unroll
-  for (int jp = 0; jp < TNP; ++jp) biasv[jp] = 0.f;
+  for (int jp = 0; jp < TNP; ++jp) {
+    biasv[jp] = 0.f;
+    scalev[jp] = p.alpha;
+  }
   if (p.bias != nullptr) {   // all loads of the pass in flight together (clamped index: no per-column branch)
 #pragma unroll
     for (int jp = 0; jp < TNP; ++jp) {
@@ -348,11 +351,18 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
       biasv[jp] = n < p.N ? b : 0.f;
     }
   }
+  if (CSTATS && p.colscale != nullptr) {   // eval-mode BatchNorm folded into the convolution: per-column scale (and bias = shift)
+#pragma unroll
+    for (int jp = 0; jp < TNP; ++jp) {
+      const int n = n0 + (wn * TN + pass * TNP + jp) * 32 + cl;
+      scalev[jp] = p.alpha * p.colscale[n < p.N ? n : 0];
+    }
+  }
 #pragma unroll
   for (int jp = 0; jp < TNP; ++jp) {
     const int j = pass * TNP + jp;
     const int ccol = (wn * TNP + jp) * 32 + cl;          // column in the staging image
-    const float bias = biasv[jp];
+    const float bias = biasv[jp], al = scalev[jp];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -366,7 +376,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
             cs1[j] += a;
             cs2[j] += a * a;
           }
-          v[r] = a * p.alpha + bias;
+          v[r] = a * al + bias;
         }
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]);
@@ -384,7 +394,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   // pre-activation) are issued first from clamped, always-valid offsets, then the transposed LDS reads, then the
   // arithmetic and the stores -- otherwise every item pays a full memory round trip in sequence.
   const bool rt_res = p.residual != nullptr, rt_relu = DGRAD && p.relu_src != nullptr, rt_pre_in = !DGRAD && p.act == 2;
-  const bool rt_pre_out = !rt_pre_in && p.preact != nullptr, rt_gelu = p.act == 1;
+  const bool rt_pre_out = !rt_pre_in && p.preact != nullptr, rt_gelu = p.act == 1, rt_rlast = CSTATS && p.act == 3;
   const int rt_nb = bnb2 ? 2 : (bnb ? 1 : 0);
   const bool cls = p.cls_h >= 0;
   // Item walk: `wave` is wave-uniform, so the item's row block / column group and everything derived from them
@@ -402,18 +412,22 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   // The hot combinations are instantiated with constants: their side loads then sit in straight-line code and are all
   // in flight together (behind run-time branches hipcc puts an `s_waitcnt vmcnt(0)` in front of every one of them,
   // i.e. one full memory round trip per load and item).
-  auto walk = [&](auto f_res, auto f_relu, auto f_pre_in, auto f_pre_out, auto f_gelu, auto f_nb) {
+  auto walk = [&](auto f_res, auto f_relu, auto f_pre_in, auto f_pre_out, auto f_gelu, auto f_nb, auto f_rlast) {
     constexpr int FRES = decltype(f_res)::value, FRELU = decltype(f_relu)::value, FPIN = decltype(f_pre_in)::value;
     constexpr int FPOUT = decltype(f_pre_out)::value, FGELU = decltype(f_gelu)::value, FNB = decltype(f_nb)::value;
-    // items in flight per wave: 4, or 2 where two BatchNorm sum sets (64 accumulators) leave no registers for more
-    constexpr int U = (DGRAD && FNB >= 2) ? 2 : 4;
+    constexpr int FRLAST = decltype(f_rlast)::value;
+    // items in flight per wave: 4, or 2 where two BatchNorm sum sets (64 accumulators), the GELU' path or the
+    // run-time-flag fallback leave no registers for more under the 12-wave (168 VGPR) budget
+    constexpr bool RUNTIME_FLAGS = FRES == 2 || FRELU == 2 || FPIN == 2 || FPOUT == 2 || FGELU == 2 || FRLAST == 2 || FNB == 3;
+    constexpr int U = ((DGRAD && FNB >= 2) || (NW_TOTAL > 8 && (RUNTIME_FLAGS || FPIN == 1))) ? 2 : 4;
     const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
     const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
     const bool has_pre_in = FPIN == 1 || (FPIN == 2 && rt_pre_in);
     const bool has_pre_out = FPOUT == 1 || (FPOUT == 2 && rt_pre_out);
     const bool has_gelu = FGELU == 1 || (FGELU == 2 && rt_gelu);
     const int nb = FNB == 3 ? rt_nb : FNB;
-    const bool ew = has_res || has_relu || has_pre_in || has_gelu || nb > 0;   // any arithmetic on the staged values
+    const bool relu_last = FRLAST == 1 || (FRLAST == 2 && rt_rlast);
+    const bool ew = has_res || has_relu || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
     for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
       unsigned o[U];
       bool ok[U];
@@ -487,6 +501,10 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
           v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
           v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
         }
+        if (relu_last) {  // forward ReLU after the residual (eval-mode conv + BatchNorm + ReLU in one launch)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if (has_relu) {  // backward of ReLU: the producer's output decides which gradients pass
           const uint4 rs = rrelu[u];
           const float y[8] = {bf16lo(rs.x), bf16hi(rs.x), bf16lo(rs.y), bf16hi(rs.y),
@@ -523,18 +541,20 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   if constexpr (DGRAD) {   // conv dgrad: [residual] [ReLU mask + 1 or 2 BatchNorm-backward sum sets]
-    if (!rt_res && !rt_relu && rt_nb == 0) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
-    else if (rt_res && !rt_relu && rt_nb == 0) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{});
-    else if (!rt_res && rt_relu && rt_nb == 1) walk(I0{}, I1{}, I0{}, I0{}, I0{}, I1{});
-    else if (rt_res && rt_relu && rt_nb == 1) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I1{});
-    else if (rt_res && rt_relu && rt_nb == 2) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I2{});
-    else walk(I2{}, I2{}, I0{}, I0{}, I0{}, I3{});
-  } else {                 // linear / conv forward / attention: [residual] | GELU [+ saved pre-activation] | * GELU'
-    if (!rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
-    else if (rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{});
-    else if (!rt_res && rt_gelu && rt_pre_out) walk(I0{}, I0{}, I0{}, I1{}, I1{}, I0{});
-    else if (!rt_res && rt_pre_in) walk(I0{}, I0{}, I1{}, I0{}, I0{}, I0{});
-    else walk(I2{}, I0{}, I2{}, I2{}, I2{}, I0{});
+    if (!rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (!rt_res && rt_relu && rt_nb == 1 && !rt_rlast) walk(I0{}, I1{}, I0{}, I0{}, I0{}, I1{}, I0{});
+    else if (rt_res && rt_relu && rt_nb == 1 && !rt_rlast) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I1{}, I0{});
+    else if (rt_res && rt_relu && rt_nb == 2 && !rt_rlast) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I2{}, I0{});
+    else walk(I2{}, I2{}, I0{}, I0{}, I0{}, I3{}, I2{});
+  } else {                 // linear / conv forward / attention: [residual] [ReLU] | GELU [+ saved pre-activation] | * GELU'
+    if (!rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu && !rt_rlast) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (rt_res && !rt_pre_in && !rt_pre_out && !rt_gelu && !rt_rlast) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    else if (!rt_res && rt_gelu && rt_pre_out) walk(I0{}, I0{}, I0{}, I1{}, I1{}, I0{}, I0{});
+    else if (!rt_res && rt_pre_in) walk(I0{}, I0{}, I1{}, I0{}, I0{}, I0{}, I0{});
+    else if (!rt_res && rt_rlast && !rt_pre_out) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I1{});
+    else if (rt_res && rt_rlast && !rt_pre_out) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{}, I1{});
+    else walk(I2{}, I0{}, I2{}, I2{}, I2{}, I0{}, I2{});
   }
   }  // pass
   if (CSTATS && p.colstats != nullptr) {
@@ -761,7 +781,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
     if constexpr (BN <= 192)
       epilogue_staged<TN, BN, BM, NW_TOTAL, GATHER == 2, GATHER == 1>(acc, p, coff, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
   } else
-    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
+    gemm_epilogue<T, TM, TN, BM / 64, BN, NTH, false>(acc, p, p.C, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane,
                                                smem, consumer);
   HTRVT_STAMP(6);
 #ifdef HTRVT_EXP_STAMP

@@ -231,7 +231,10 @@ class Engine:
         if dbias is not None:
             check(lib.htrvt_colsum(ptr(dy), M, N, N, ptr(dbias), None, 1, self.dti, stream()), "colsum")
 
-    def conv_fwd(self, x, wf, g: ConvGeom, want_stats):
+    def conv_fwd(self, x, wf, g: ConvGeom, want_stats, bn=None, relu=False, residual=None):
+        """bn = (scale, shift): eval-mode BatchNorm (running statistics) folded into the launch -- C = relu?(conv * scale +
+        shift [+ residual]) -- instead of a raw conv output plus a BatchNorm pass (train mode needs the batch statistics
+        of the whole output first)."""
         M = g.B * g.Ho * g.Wo
         cpi = cpad(g.Ci, self.dtype)
         y = self._empty(g.B, g.Ho, g.Wo, g.Co)
@@ -239,8 +242,11 @@ class Engine:
         if want_stats:
             rows = ops.gemm_num_mtiles(M, g.Co, self.dtype, gather=GATHER_CONV_FWD)
             cs = self._empty(rows + 64, 2, g.Co, dtype=torch.float32)
+        kw = {}
+        if bn is not None:
+            kw = dict(colscale=bn[0], bias=bn[1], residual=residual, act=3 if relu else 0)
         gemm(x, wf, y, dtype=self.dtype, M=M, N=g.Co, K=g.taps * cpi, lda=g.Ci, ldb=g.taps * cpi, ldc=g.Co,
-             gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs)
+             gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs, **kw)
         return y, cs, rows
 
     def dgrad_tiles(self, g: ConvGeom):
@@ -403,11 +409,27 @@ class Engine:
                 strd = stride if bi == 0 else (1, 1)
                 g1 = ConvGeom(B, Hc, Wc, Cin, planes, 3, strd, 1)
                 wf1, _ = self._conv_w(p + ".conv1", P[p + ".conv1.weight"])
+                g2 = ConvGeom(B, g1.Ho, g1.Wo, planes, planes, 3, (1, 1), 1)
+                wf2, _ = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
+                if not train and not save:
+                    # eval: running statistics are known up front, every BatchNorm (+ residual + ReLU) rides in the
+                    # epilogue of its convolution: 2-3 launches per block, no normalisation passes
+                    bn_a = self.bn_coeffs(P, p + ".bn1", planes, False)
+                    a1, _, _ = self.conv_fwd(x, wf1, g1, False, bn=bn_a, relu=True)
+                    bn_b = self.bn_coeffs(P, p + ".bn2", planes, False)
+                    res = x
+                    if bi == 0:
+                        gd = ConvGeom(B, Hc, Wc, Cin, planes, 1, strd, 0)
+                        wfd, _ = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
+                        bn_d = self.bn_coeffs(P, p + ".downsample.1", planes, False)
+                        res, _, _ = self.conv_fwd(x, wfd, gd, False, bn=bn_d)
+                    out, _, _ = self.conv_fwd(a1, wf2, g2, False, bn=bn_b, relu=True, residual=res)
+                    x = out
+                    Hc, Wc, Cin = g1.Ho, g1.Wo, planes
+                    continue
                 ca, cs1, r1 = self.conv_fwd(x, wf1, g1, train)
                 bn_a = self.bn_coeffs(P, p + ".bn1", planes, train, cs1, r1, B * g1.Ho * g1.Wo)
                 a1 = self.bn_apply(ca, bn_a[0], bn_a[1], relu=True)
-                g2 = ConvGeom(B, g1.Ho, g1.Wo, planes, planes, 3, (1, 1), 1)
-                wf2, _ = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
                 cb, cs2, r2 = self.conv_fwd(a1, wf2, g2, train)
                 bn_b = self.bn_coeffs(P, p + ".bn2", planes, train, cs2, r2, B * g2.Ho * g2.Wo)
                 if bi == 0:

@@ -66,7 +66,7 @@ class ConvGeom:
 
 def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
          Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
-         accumulate=False, bias=None, preact=None, residual=None, colstats=None, tile=0,
+         accumulate=False, bias=None, colscale=None, preact=None, residual=None, colstats=None, tile=0,
          a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0):
     """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
     is used); *_off are element offsets into them."""
@@ -90,6 +90,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.accumulate = 1 if accumulate else 0
     d.tile = tile or _ENV_TILE     # HTRVT_GEMM_TILE: force a kernel variant (A/B runs, tests of non-default variants)
     d.bias = ptr(bias)
+    d.colscale = ptr(colscale)
     d.preact = ptr(preact)
     d.residual = ptr(residual)
     d.colstats = ptr(colstats)

@@ -62,11 +62,12 @@ typedef struct HtrvtGemmDesc {
   int32_t cls_h, cls_w;
   /* epilogue */
   float alpha;
-  int32_t act;              /* 0 none, 1 exact-erf GELU                              */
+  int32_t act;              /* 0 none, 1 exact-erf GELU, 2 multiply by GELU'(preact), 3 ReLU applied last (after residual) */
   int32_t c_f32;            /* 1: C (and residual) are float32 regardless of dtype  */
   int32_t accumulate;       /* 1: atomicAdd into float32 C                           */
   int32_t tile;             /* 0 auto; else BM*1000+BN of a built instantiation     */
   const float* bias;        /* [N] or NULL                                           */
+  const float* colscale;    /* [N] or NULL: C = alpha*acc*colscale[n] + bias[n] (eval-mode BatchNorm folded into the conv) */
   void* preact;             /* same shape/type as C: value before `act`, or NULL     */
   const void* residual;     /* same shape/type as C, added last, or NULL             */
   float* colstats;          /* [ceil(M/BM)][2][N]: per-M-tile column sum / sum of squares of the

@@ -56,6 +56,30 @@ def test_nt_epilogue(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N", [(512, 192), (300, 136), (1024, 384)])
+def test_nt_colscale_bias_residual_relu_exact(dtype, M, N):
+    """eval-mode BatchNorm folded into the launch: C = relu(acc * colscale[n] + bias[n] + residual); integer operands and
+    power-of-two scales keep every step exact (values stay below the bf16 integer range)"""
+    ops = _ops()
+    K = 64
+    A, B = _ints((M, K), lo=-2, hi=3, seed=4), _ints((N, K), lo=-2, hi=3, seed=5)
+    g = torch.Generator().manual_seed(6)
+    scale = torch.tensor([0.25, 0.5, 1.0, -0.5])[torch.randint(0, 4, (N,), generator=g)].double()
+    bias = torch.randint(-8, 9, (N,), generator=g).double()
+    res = torch.randint(-16, 17, (M, N), generator=g).double()
+    a, b = A.to(dtype).cuda(), B.to(dtype).cuda()
+    pre = (A @ B.t()) * scale + bias
+    for with_res, relu in ((False, False), (False, True), (True, True)):
+        ref = pre.to(dtype).double() + (res if with_res else 0.0)      # the staged value is rounded before the residual
+        if relu:
+            ref = ref.clamp_min(0.0)
+        c = torch.empty(M, N, dtype=dtype, device="cuda")
+        ops.gemm(a, b, c, dtype=dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, colscale=scale.float().cuda(),
+                 bias=bias.float().cuda(), residual=res.to(dtype).cuda() if with_res else None, act=3 if relu else 0)
+        assert torch.equal(c.double().cpu(), ref.to(dtype).double()), (with_res, relu)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_nn_and_tn_exact(dtype):
     ops = _ops()
     M, N, K = 160, 96, 72

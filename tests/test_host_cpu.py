@@ -140,3 +140,21 @@ def test_dp_gradient_buckets_gloo_world2():
         same_params, ok, enc_ok, enc_start = res[r]
         assert same_params and ok and enc_ok and enc_start > 0
     assert res[0][3] == res[1][3]
+
+
+def test_no_kernel_runs_on_scratch():
+    """a GEMM kernel that falls back to scratch memory (SGPR / VGPR spills past the register file) still computes the
+    right numbers but runs several times slower: the layer-3 weight gradient once went from 0.63 to 2.76 ms that way.
+    Allowed: the few-dword spills of the register-tight 12-wave variants (epilogue only, <= 32 bytes)."""
+    import shutil
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "check_kernels.sh")
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and shutil.which("bash")):
+        pytest.skip("ROCm llvm tools not available")
+    out = subprocess.run(["bash", tool], capture_output=True, text=True, timeout=300).stdout
+    worst = 0
+    for line in out.splitlines():
+        parts = line.split()
+        if "scratch" in parts:
+            worst = max(worst, int(parts[parts.index("scratch") + 1]))
+    assert worst <= 32, out

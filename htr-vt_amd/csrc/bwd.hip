@@ -46,7 +46,8 @@ __global__ __launch_bounds__(NT) void seq_whiten_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename T>
+// NK = ceil(D / CH / 64): 16-byte chunks per lane, a compile-time constant so that every load of a row is in straight-line code
+template <typename T, int NK>
 __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const T* __restrict__ dres,
@@ -57,27 +58,47 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const T* __restrict__
   float* red = reinterpret_cast<float*>(smem_raw);  // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / CH;
-  float ag[MAXC][CH], ab[MAXC][CH];
+  float ag[NK][CH], ab[NK][CH];
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k)
+  for (int k = 0; k < NK; ++k)
 #pragma unroll
     for (int j = 0; j < CH; ++j) ag[k][j] = ab[k][j] = 0.f;
 
+  // gamma of this lane's chunks lives in registers; all loads of a row (x, dy, dres) go out together from clamped,
+  // always-valid offsets (behind `if (c < nchunk)` hipcc waits for each load before issuing the next one)
+  using Raw = decltype(Vec16<T>().raw);
+  float gm[NK][CH];
+  bool act[NK];
+  int cc[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c = lane + 64 * k;
+    act[k] = c < nchunk;
+    cc[k] = act[k] ? c : 0;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) gm[k][j] = act[k] ? gamma[c * CH + j] : 0.f;
+  }
   for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
     const float mu = mean[row], r = rstd[row];
-    Vec16<T> vx[MAXC], vd[MAXC];
+    Vec16<T> vx[NK], vd[NK], dr[NK];
+    const Raw* xr = reinterpret_cast<const Raw*>(x + row * D);
+    const Raw* dyr = reinterpret_cast<const Raw*>(dy + row * D);
+    const Raw* drr = reinterpret_cast<const Raw*>(dres + row * D);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      vx[k].raw = xr[cc[k]];
+      vd[k].raw = dyr[cc[k]];
+      if (dres) dr[k].raw = drr[cc[k]];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int c = lane + 64 * k;
-      if (c < nchunk) {
-        vx[k].raw = reinterpret_cast<const decltype(vx[k].raw)*>(x + row * D)[c];
-        vd[k].raw = reinterpret_cast<const decltype(vd[k].raw)*>(dy + row * D)[c];
+    for (int k = 0; k < NK; ++k) {
+      {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float xh = (vx[k].get(j) - mu) * r;
-          const float d = vd[k].get(j);
-          const float g = d * gamma[c * CH + j];
+          const float d = act[k] ? vd[k].get(j) : 0.f;
+          const float g = d * gm[k][j];
           s1 += g;
           s2 += g * xh;
           ag[k][j] += d * xh;
@@ -87,25 +108,23 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const T* __restrict__
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int c = lane + 64 * k;
-      if (c < nchunk) {
-        Vec16<T> o, dr;
-        if (dres) dr.raw = reinterpret_cast<const decltype(dr.raw)*>(dres + row * D)[c];
+    for (int k = 0; k < NK; ++k) {
+      {
+        Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float xh = (vx[k].get(j) - mu) * r;
-          float v = r * (vd[k].get(j) * gamma[c * CH + j] - m1 - xh * m2);
-          if (dres) v += dr.get(j);
+          float v = r * (vd[k].get(j) * gm[k][j] - m1 - xh * m2);
+          if (dres) v += dr[k].get(j);
           o.set(j, v);
         }
-        reinterpret_cast<decltype(o.raw)*>(dx + row * D)[c] = o.raw;
+        if (act[k]) reinterpret_cast<Raw*>(dx + row * D)[lane + 64 * k] = o.raw;
       }
     }
   }
   // block partial of dgamma / dbeta
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
+  for (int k = 0; k < NK; ++k) {
     const int c = lane + 64 * k;
     if (c < nchunk) {
 #pragma unroll
@@ -664,8 +683,16 @@ extern "C" int htrvt_layernorm_bwd(const void* dy, const void* x, const float* m
   const size_t smem = (size_t)8 * D * 4;
   HTRVT_REQUIRE(smem <= 64 * 1024, "htrvt_layernorm_bwd: D=%d too large", D);
   dim3 grid(htrvt_layernorm_bwd_blocks(rows));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, grid, dim3(NT), smem, (hipStream_t)stream, (const T*)dy,
-                                       (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, partial, (long long)rows, D));
+  const int nk = (D / ch + 63) / 64;
+#define LN_BWD(NKV)                                                                                                      \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NKV>), grid, dim3(NT), smem, (hipStream_t)stream,         \
+                                       (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, partial,      \
+                                       (long long)rows, D))
+  if (nk == 1) LN_BWD(1);
+  else if (nk == 2) LN_BWD(2);
+  else if (nk == 3) LN_BWD(3);
+  else LN_BWD(4);
+#undef LN_BWD
   return check_launch("layernorm_bwd");
 }
 

@@ -123,6 +123,7 @@ def main():
         dw = torch.zeros(g.taps, Ci, Co, dtype=torch.float32, device=dev)
         from htrvt_amd.engine import Engine, ModelShape
         split = Engine(ModelShape(80, (64, 1024), 768, 4, 6), dt)._split_k(g.taps * Ci, Co, M, conv=True)
+        split = int(os.environ.get('HTRVT_BENCH_SPLITK', split))
         ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
                                      b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci, split_k=split,
                                      accumulate=True, c_f32=True), args.iters)

@@ -5,7 +5,6 @@
 namespace htrvt {
 int gemm_dma_dispatch_bn192(const HtrvtGemmDesc* d, const KParams& p, int zdim, hipStream_t st, bool spec) {
   if (spec) return dispatch<256, 192, 1>(d, p, zdim, st);
-  (void)spec;
   return dispatch<256, 192, 0>(d, p, zdim, st);
 }
 }  // namespace htrvt

@@ -707,48 +707,58 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const unsigned lds0 = lds_addr_of(smem);
   constexpr bool KMAP = (GATHER == 1 || GATHER == 2);
-  // every DMA-issuing wave issues exactly PER_TILE pieces per k-tile, so "all but the youngest tile have landed" is
-  // s_waitcnt vmcnt(PER_TILE) for it (consumer-only waves have nothing outstanding)
-  constexpr int PER_TILE = DmaLoader<BM, AL, GATHER, NWL>::NP + DmaLoader<BN, BL, 0, NWL>::NP;
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "two or three LDS stages");
+  // every DMA-issuing wave issues exactly NP_A + NP_B pieces per k-tile, so "all but the youngest pieces have landed"
+  // is a counted s_waitcnt vmcnt for it (consumer-only waves have nothing outstanding)
+  constexpr int NP_A = DmaLoader<BM, AL, GATHER, NWL>::NP, NP_B = DmaLoader<BN, BL, 0, NWL>::NP;
+  constexpr int PER_TILE = NP_A + NP_B;
+  static_assert(NSTAGE == 2 || NSTAGE == 3 || NSTAGE == 5, "2, 3, or 3 (A) + 2 (B) LDS stages");
   static_assert(PER_TILE <= 63, "vmcnt immediate");
+  // LDS: [AST buffers of A][BST buffers of B]
+  constexpr int AST = NSTAGE == 5 ? 3 : NSTAGE, BST = NSTAGE == 5 ? 2 : NSTAGE;
+  constexpr unsigned B_BASE = AST * A_BYTES;
+  // NSTAGE == 5, the 256x192 tile's budget (3 x 32 KB + 2 x 24 KB = 144 KB): A runs two k-tiles ahead, B one.  Per
+  // iteration the loaders issue B(t+1) first, then A(t+2); before the barrier everything but the youngest NP_A pieces
+  // (= A(t+2)) must have landed, so only B's 24 KB are latency-critical and A(t+2) flies across the barrier.
+  // Measured (dispatch<256, 192, SPEC, 5>, not instantiated in the shipped library): within +-2 % of two stages on every
+  // shape of the step -- the round trip of the ONE tile that is not two ahead still bounds the loop; only the full
+  // third stage (NSTAGE == 3, tiles of <= 128 columns) pays.
   if (loader) {
-#pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t) {
-      if (t < nkt) {
-        la.issue(p, lds0 + t * STAGE, kbeg + t * BK, kend, lw);
-        lb.template issue<KMAP>(p, lds0 + t * STAGE + A_BYTES, kbeg + t * BK, kend, lw);
-      }
+    if (nkt > 0) {
+      la.issue(p, lds0, kbeg, kend, lw);
+      lb.template issue<KMAP>(p, lds0 + B_BASE, kbeg, kend, lw);
+    }
+    if (AST == 3 && nkt > 1) {
+      la.issue(p, lds0 + A_BYTES, kbeg + BK, kend, lw);
+      if (BST == 3) lb.template issue<KMAP>(p, lds0 + B_BASE + B_BYTES, kbeg + BK, kend, lw);
     }
   }
   HTRVT_STAMP(1);
   if (NSTAGE == 3 && nkt > 1)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+  else if (NSTAGE == 5 && nkt > 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP_A) : "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   HTRVT_STAMP(2);
 
-  int s_cur = 0, s_nxt = NSTAGE - 1;   // stage being multiplied / stage the DMA issued in this iteration fills
+  int a_cur = 0, a_nxt = AST - 1;   // A buffer being multiplied / A buffer the DMA issued in this iteration fills
+  int b_cur = 0, b_nxt = BST - 1;
   for (int kt = 0; kt < nkt; ++kt) {
-    char* cur = smem + s_cur * STAGE;
-    const unsigned nxt = lds0 + s_nxt * STAGE;
-    const int kt_issue = kt + NSTAGE - 1;
-#ifdef HTRVT_EXP_NODMA
-    if (false) {
-#else
-    if (loader && kt_issue < nkt) {  // this DMA flies during the MFMAs of this and (three stages) the next k-tile
-#endif
-      la.issue(p, nxt, kbeg + kt_issue * BK, kend, lw);
-      lb.template issue<KMAP>(p, nxt + A_BYTES, kbeg + kt_issue * BK, kend, lw);
+    const char* sa = smem + a_cur * A_BYTES;
+    const char* sb = smem + B_BASE + b_cur * B_BYTES;
+    const int kt_a = kt + AST - 1, kt_b = kt + BST - 1;
+#ifndef HTRVT_EXP_NODMA
+    if (loader) {   // B first: its (shorter) run-ahead makes it the latency-critical one
+      if (kt_b < nkt) lb.template issue<KMAP>(p, lds0 + B_BASE + b_nxt * B_BYTES, kbeg + kt_b * BK, kend, lw);
+      if (kt_a < nkt) la.issue(p, lds0 + a_nxt * A_BYTES, kbeg + kt_a * BK, kend, lw);
     }
+#endif
 #ifdef HTRVT_EXP_NOMMA
     if (false) {
 #else
     if (consumer) {
 #endif
-      const char* sa = cur;
-      const char* sb = cur + A_BYTES;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bf16x8_t fa[TM], fb[TN];
@@ -763,14 +773,18 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    // k-tile kt+1 must have landed before the barrier; with three stages the tile issued above may stay in flight
-    if (NSTAGE == 3 && kt_issue < nkt)
+    // k-tile kt+1 must have landed before the barrier; what was issued for k-tile kt+2 may stay in flight
+    if (NSTAGE == 3 && kt_a < nkt)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    else if (NSTAGE == 5 && kt_a < nkt)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP_A) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    s_cur = (s_cur + 1 == NSTAGE) ? 0 : s_cur + 1;
-    s_nxt = (s_nxt + 1 == NSTAGE) ? 0 : s_nxt + 1;
+    a_cur = (a_cur + 1 == AST) ? 0 : a_cur + 1;
+    a_nxt = (a_nxt + 1 == AST) ? 0 : a_nxt + 1;
+    b_cur = (b_cur + 1 == BST) ? 0 : b_cur + 1;
+    b_nxt = (b_nxt + 1 == BST) ? 0 : b_nxt + 1;
   }
 
   HTRVT_STAMP(3);
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
 template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>
 int launch(const KParams& p, int zdim, hipStream_t st) {
   constexpr int NTH = BM * 2 + SPEC * 256;
-  constexpr int smem = NSTAGE * (Geo<BM>::BYTES + Geo<BN>::BYTES);
+  constexpr int smem = NSTAGE == 5 ? 3 * Geo<BM>::BYTES + 2 * Geo<BN>::BYTES : NSTAGE * (Geo<BM>::BYTES + Geo<BN>::BYTES);
   static_assert(smem <= 160 * 1024, "LDS");
   static bool attr_done = false;
   auto kern = gemm_dma_kernel<BM, BN, AL, BL, GATHER, SPEC, NSTAGE>;

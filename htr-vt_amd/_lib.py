@@ -44,8 +44,8 @@ PROTOTYPES = {
     "htrvt_last_error": (C.c_char_p, []),
     "htrvt_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
-    "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, vp]),
-    "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),
+    "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, vp]),
     "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
@@ -68,9 +68,9 @@ PROTOTYPES = {
     "htrvt_pool_tokens_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_conv1_bwd_rows": (i32, [i32, i32]),
     "htrvt_conv1_bwd_row_floats": (i32, [i32]),
-    "htrvt_conv1_bwd": (i32, [vp] * 12 + [i32, i32, i32, i32, i32, vp]),
+    "htrvt_conv1_bwd": (i32, [vp] * 12 + [i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_conv1_wgrad_blocks": (i32, [i32, i32]),
-    "htrvt_conv1_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_conv1_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),

@@ -498,9 +498,9 @@ __global__ __launch_bounds__(NT) void pool_tokens_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------ conv1 weight gradient (Cin = 1)
 // partial[blk][C*9] = sum over the block's output rows of dY[pix][c] * whitened tap
 template <typename T>
-__global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ stats,
+__global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const void* __restrict__ img, const float* __restrict__ stats,
                                                          const T* __restrict__ dy, float* __restrict__ partial, int B,
-                                                         int H, int W, int C, int nthr) {
+                                                         int H, int W, int C, int nthr, int u8) {
   constexpr int CH = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2], later reduction scratch
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const float* __restrict
       const int r = i / WP, c = i - r * WP;
       const int hi = 2 * ho - 1 + r, wi = c - 1;
       float v = 0.f;
-      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (img[((long long)b * H + hi) * W + wi] - mean) * rstd;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
       rows[i] = v;
     }
     __syncthreads();
@@ -791,8 +791,8 @@ extern "C" int htrvt_conv1_wgrad_blocks(int B, int H) {
   return g > 512 ? 512 : g;
 }
 
-extern "C" int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, float* dw, float* partial, int B,
-                                 int H, int W, int C, int dtype, void* stream) {
+extern "C" int htrvt_conv1_wgrad(const void* img, const float* stats, const void* dy, float* dw, float* partial, int B,
+                                 int H, int W, int C, int dtype, int img_u8, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0, "htrvt_conv1_wgrad: C=%d unsupported", C);
   const int cvec = C / ch, nthr = (NT / cvec) * cvec;
@@ -802,7 +802,7 @@ extern "C" int htrvt_conv1_wgrad(const float* img, const float* stats, const voi
   hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblk * C * 9 * 4, st);
   HTRVT_REQUIRE(e == hipSuccess, "htrvt_conv1_wgrad: memset failed: %s", hipGetErrorString(e));
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_wgrad_kernel<T>, dim3(nblk), dim3(NT), smem, st, img, stats, (const T*)dy,
-                                       partial, B, H, W, C, nthr));
+                                       partial, B, H, W, C, nthr, img_u8));
   hipLaunchKernelGGL(rowsum_f32_kernel, dim3((C * 9 + NT - 1) / NT), dim3(NT), 0, st, partial, nblk, C * 9, dw);
   return check_launch("conv1_wgrad");
 }

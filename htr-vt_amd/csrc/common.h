@@ -33,6 +33,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)from_f32<bf16_t>(lo).v | ((unsigned)from_f32<bf16_t>(hi).v << 16);
 }
 
+// pixel i of an image batch that is float32, or uint8 taken as value / 255 (torchvision ToTensor: the uint8 -> float
+// hand-off of the reference's data pipeline, data/dataset.py, fused into the first kernels that touch the image)
+__device__ __forceinline__ float load_pixel(const void* img, long long i, int u8) {
+  return u8 ? (float)reinterpret_cast<const unsigned char*>(img)[i] / 255.0f : reinterpret_cast<const float*>(img)[i];
+}
+
 // 16-byte vector of T
 template <typename T>
 struct Vec16;

@@ -23,10 +23,10 @@ constexpr int NIMG = 54;  // 9 tap sums + 45 upper-triangle tap products
 // touch (zero halo = zero padding in whitened space).  A wave is CGW channel vectors x 64/CGW pixel lanes: adjacent
 // lanes read adjacent 16-byte channel vectors of one pixel (coalesced), the pixel lanes march along the row.
 template <typename T>
-__global__ __launch_bounds__(512) void conv1_bwd_kernel(const float* __restrict__ img, const float* __restrict__ stats,
+__global__ __launch_bounds__(512) void conv1_bwd_kernel(const void* __restrict__ img, const float* __restrict__ stats,
                                                          const T* __restrict__ dpool, const unsigned char* __restrict__ idx,
                                                          float* __restrict__ partial, int H, int W, int C, int cgw,
-                                                         int ld) {
+                                                         int ld, int u8) {
   constexpr int CH = Vec16<T>::N;
   using Raw = decltype(Vec16<T>().raw);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void conv1_bwd_kernel(const float* __restrict_
     const int r = i / WP, c = i - r * WP;
     const int hi = 4 * ph - 3 + r, wi = c - 2;
     float v = 0.f;
-    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (img[((long long)b * H + hi) * W + wi] - mean) * rstd;
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
     rows[i] = v;
   }
   __syncthreads();
@@ -213,9 +213,9 @@ extern "C" int htrvt_conv1_bwd_rows(int B, int H) {
   return B * Hp + S_ROWS;
 }
 
-extern "C" int htrvt_conv1_bwd(const float* img, const float* stats, const void* dpool, const uint8_t* idx, const float* w,
+extern "C" int htrvt_conv1_bwd(const void* img, const float* stats, const void* dpool, const uint8_t* idx, const float* w,
                                const float* gamma, const float* mean, const float* rstd, float* partial, float* dw,
-                               float* dgamma, float* dbeta, int B, int H, int W, int C, int dtype, void* stream) {
+                               float* dgamma, float* dbeta, int B, int H, int W, int C, int dtype, int img_u8, void* stream) {
   const int CH = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(dtype == HTRVT_BF16 || dtype == HTRVT_F32, "conv1_bwd: bad dtype %d", dtype);
   HTRVT_REQUIRE(B > 0 && H >= 4 && H % 2 == 0 && W > 0 && C > 0 && C % CH == 0, "conv1_bwd: bad shape B=%d H=%d W=%d C=%d", B,
@@ -233,12 +233,12 @@ extern "C" int htrvt_conv1_bwd(const float* img, const float* stats, const void*
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)smem);
-    conv1_bwd_kernel<bf16_t><<<nrows, nw * 64, smem, st>>>(img, stats, (const bf16_t*)dpool, idx, partial, H, W, C, cgw, ld);
+    conv1_bwd_kernel<bf16_t><<<nrows, nw * 64, smem, st>>>(img, stats, (const bf16_t*)dpool, idx, partial, H, W, C, cgw, ld, img_u8);
   } else {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)smem);
-    conv1_bwd_kernel<float><<<nrows, nw * 64, smem, st>>>(img, stats, (const float*)dpool, idx, partial, H, W, C, cgw, ld);
+    conv1_bwd_kernel<float><<<nrows, nw * 64, smem, st>>>(img, stats, (const float*)dpool, idx, partial, H, W, C, cgw, ld, img_u8);
   }
   float* red = partial + (long long)nrows * ld;
   conv1_bwd_reduce_kernel<<<dim3((ld + 63) / 64, S_ROWS), 256, 0, st>>>(partial, red, nrows, ld);

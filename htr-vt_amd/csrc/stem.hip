@@ -13,20 +13,37 @@ constexpr int NT = 256;
 
 // ------------------------------------------------------------------ img_stats
 // one block per image; two passes (mean, then centred variance) -> {mean, rstd}
-__global__ __launch_bounds__(NT) void img_stats_kernel(const float* __restrict__ img, float* __restrict__ stats, int HW,
-                                                       float eps) {
+__global__ __launch_bounds__(NT) void img_stats_kernel(const void* __restrict__ img, float* __restrict__ stats, int HW,
+                                                       float eps, int u8) {
   __shared__ float red[8];
-  const float* x = img + (long long)blockIdx.x * HW;
+  const long long base = (long long)blockIdx.x * HW;
+  auto load4 = [&](int i, float (&v)[4]) {
+    if (u8) {
+      const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const unsigned char*>(img) + base + i);
+      v[0] = (float)q.x / 255.0f;
+      v[1] = (float)q.y / 255.0f;
+      v[2] = (float)q.z / 255.0f;
+      v[3] = (float)q.w / 255.0f;
+    } else {
+      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(img) + base + i);
+      v[0] = q.x;
+      v[1] = q.y;
+      v[2] = q.z;
+      v[3] = q.w;
+    }
+  };
   float s = 0.f;
   for (int i = threadIdx.x * 4; i < HW; i += NT * 4) {
-    const float4 v = *reinterpret_cast<const float4*>(x + i);
-    s += (v.x + v.y) + (v.z + v.w);
+    float v[4];
+    load4(i, v);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
   }
   const float mean = block_sum_256(s, red) / (float)HW;
   float q = 0.f;
   for (int i = threadIdx.x * 4; i < HW; i += NT * 4) {
-    const float4 v = *reinterpret_cast<const float4*>(x + i);
-    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    float v[4];
+    load4(i, v);
+    const float a = v[0] - mean, b = v[1] - mean, c = v[2] - mean, d = v[3] - mean;
     q += (a * a + b * b) + (c * c + d * d);
   }
   const float var = block_sum_256(q, red) / (float)HW;
@@ -41,9 +58,9 @@ __global__ __launch_bounds__(NT) void img_stats_kernel(const float* __restrict__
 // halo = zero padding in whitened space); each thread owns CH consecutive output
 // channels (weights in registers) and walks the row's pixels.
 template <typename T>
-__global__ __launch_bounds__(NT) void conv1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ stats,
+__global__ __launch_bounds__(NT) void conv1_fwd_kernel(const void* __restrict__ img, const float* __restrict__ stats,
                                                        const float* __restrict__ w, T* __restrict__ out,
-                                                       float* __restrict__ colstats, int H, int W, int C, int nthr) {
+                                                       float* __restrict__ colstats, int H, int W, int C, int nthr, int u8) {
   constexpr int CH = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2]
@@ -55,7 +72,7 @@ __global__ __launch_bounds__(NT) void conv1_fwd_kernel(const float* __restrict__
     const int r = i / WP, c = i - r * WP;
     const int hi = 2 * ho - 1 + r, wi = c - 1;
     float v = 0.f;
-    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (img[((long long)b * H + hi) * W + wi] - mean) * rstd;
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
     rows[i] = v;
   }
   __syncthreads();
@@ -351,14 +368,14 @@ inline int grid_for(long long work_items) {
 
 }  // namespace
 
-extern "C" int htrvt_img_stats(const float* img, float* stats, int B, int HW, float eps, void* stream) {
+extern "C" int htrvt_img_stats(const void* img, float* stats, int B, int HW, float eps, int img_u8, void* stream) {
   HTRVT_REQUIRE(HW % 4 == 0 && B > 0, "htrvt_img_stats: HW must be a multiple of 4");
-  hipLaunchKernelGGL(img_stats_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, img, stats, HW, eps);
+  hipLaunchKernelGGL(img_stats_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, img, stats, HW, eps, img_u8);
   return check_launch("img_stats");
 }
 
-extern "C" int htrvt_conv1_fwd(const float* img, const float* stats, const float* w, void* out, float* colstats, int B,
-                               int H, int W, int C, int dtype, void* stream) {
+extern "C" int htrvt_conv1_fwd(const void* img, const float* stats, const float* w, void* out, float* colstats, int B,
+                               int H, int W, int C, int dtype, int img_u8, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0, "htrvt_conv1_fwd: C=%d must be a multiple of %d and <= %d", C, ch,
                 NT * ch);
@@ -370,10 +387,10 @@ extern "C" int htrvt_conv1_fwd(const float* img, const float* stats, const float
   dim3 grid(B * (H / 2));
   if (dtype == HTRVT_BF16)
     hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, (bf16_t*)out,
-                       colstats, H, W, C, nthr);
+                       colstats, H, W, C, nthr, img_u8);
   else
     hipLaunchKernelGGL(conv1_fwd_kernel<float>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, (float*)out,
-                       colstats, H, W, C, nthr);
+                       colstats, H, W, C, nthr, img_u8);
   return check_launch("conv1_fwd");
 }
 

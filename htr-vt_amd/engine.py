@@ -373,7 +373,8 @@ class Engine:
         img: [B,1,H,W] float32.  keep_mask: None or float32 [N] (1 keep / 0 mask-token).
         Returns float32 logits [B,N,nb_cls] (after the final param-free LayerNorm)."""
         s = self.s
-        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        assert img.is_cuda and img.dtype in (torch.float32, torch.uint8) and img.is_contiguous()
+        u8 = 1 if img.dtype == torch.uint8 else 0    # uint8 pixels are read as value / 255 (ToTensor) by the first kernels
         B, _, H, W = img.shape
         assert (H, W) == (s.H, s.W), f"model built for {s.H}x{s.W}, got {H}x{W}"
         st = stream()
@@ -385,11 +386,11 @@ class Engine:
 
         # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
         stats = self._empty(B, 2, dtype=torch.float32)
-        check(lib.htrvt_img_stats(ptr(img), ptr(stats), B, H * W, WHITEN_EPS, st), "img_stats")
+        check(lib.htrvt_img_stats(ptr(img), ptr(stats), B, H * W, WHITEN_EPS, u8, st), "img_stats")
         c1 = self._empty(B, H // 2, W, C1)
         cs = self._empty(B * (H // 2) + 64, 2, C1, dtype=torch.float32) if train else self._empty(B * (H // 2), 2, C1, dtype=torch.float32)
         w1 = P["patch_embed.conv1.weight"]
-        check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, st), "conv1_fwd")
+        check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, u8, st), "conv1_fwd")
         sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W)
         Hp = (H // 2 - 1) // 2 + 1
         a = self._empty(B, Hp, W, C1)
@@ -671,6 +672,7 @@ class Engine:
 
         # first maxpool + bn1 + conv1
         img, c1 = sv["img"], sv["c1"]
+        u8 = 1 if img.dtype == torch.uint8 else 0
         sc, sf, mean, rstd = sv["bn1"]
         _, Hh, W, C1 = c1.shape
         if self.fuse_conv1_backward:
@@ -679,7 +681,7 @@ class Engine:
             check(lib.htrvt_conv1_bwd(ptr(img), ptr(sv["stats"]), ptr(dout), ptr(sv["idx"]), ptr(P["patch_embed.conv1.weight"]),
                                       ptr(P["patch_embed.bn1.weight"]), ptr(mean), ptr(rstd), ptr(partial),
                                       ptr(G["patch_embed.conv1.weight"]), ptr(G["patch_embed.bn1.weight"]),
-                                      ptr(G["patch_embed.bn1.bias"]), B, 2 * Hh, W, C1, self.dti, st), "conv1_bwd")
+                                      ptr(G["patch_embed.bn1.bias"]), B, 2 * Hh, W, C1, self.dti, u8, st), "conv1_bwd")
         else:
             g = torch.empty_like(c1)
             check(lib.htrvt_maxpool_bwd(ptr(dout), ptr(sv["idx"]), ptr(c1), ptr(sc), ptr(sf), ptr(g), B, Hh, W, C1, self.dti, st),
@@ -689,7 +691,7 @@ class Engine:
             nblk = lib.htrvt_conv1_wgrad_blocks(B, 2 * Hh)
             partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
             check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
-                                        B, 2 * Hh, W, C1, self.dti, st), "conv1_wgrad")
+                                        B, 2 * Hh, W, C1, self.dti, u8, st), "conv1_wgrad")
         self._join_side()
         self._side_active = False
         self._zarena_end()

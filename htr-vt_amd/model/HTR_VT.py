@@ -3,7 +3,7 @@
 Drop-in for /root/reference/model_v1/model/HTR_VT.py:
     create_model(nb_cls, img_size, **kwargs) -> nn.Module            (HTR_VT.py:244-254)
     module(x, mask_ratio=0.0, max_span_length=1, use_masking=False)  (HTR_VT.py:222-241)
-        x: [B,1,H,W] float32 -> logits [B,N,nb_cls] float32
+        x: [B,1,H,W] float32 (or uint8 grey levels, read as value / 255) -> logits [B,N,nb_cls] float32
 Same module tree, parameter names/shapes (150-tensor state_dict at d768) and the
 same construction order, so `torch.manual_seed(s); create_model(...)` yields the
 reference's initial weights and `load_state_dict(strict=True)` of a reference
@@ -168,7 +168,8 @@ class MaskedAutoencoderViT(nn.Module):
         for n, t in self.state_dict(keep_vars=True).items():
             names.append(n)
             tensors.append(t)
-        x = x.contiguous().float()
+        # uint8 images (the data pipeline's raw grey levels) stay uint8: the first kernels read them as value / 255
+        x = x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float()
         return _HTRVTFunction.apply(self, x, keep_mask, self.training, tuple(names), *tensors)
 
 

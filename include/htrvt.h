@@ -93,12 +93,15 @@ int htrvt_gemm(const HtrvtGemmDesc* d, void* stream);
 int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d);
 
 /* ---- stem helpers (resnet18.py:42-84, HTR_VT.py:134-136,224-227) ------------- */
-/* per-image mean / rstd of the raw image (param-free LayerNorm, eps 1e-5): stats[b] = {mean, rstd} */
-int htrvt_img_stats(const float* img, float* stats, int B, int HW, float eps, void* stream);
+/* per-image mean / rstd of the raw image (param-free LayerNorm, eps 1e-5): stats[b] = {mean, rstd}.
+ * img_u8 (here and in the conv1 entry points): 0 = float32 pixels; 1 = uint8 pixels taken as value / 255, i.e. the
+ * torchvision ToTensor hand-off of the reference's data pipeline (data/dataset.py) fused into the first reads of the
+ * image -- a quarter of the host->device bytes. */
+int htrvt_img_stats(const void* img, float* stats, int B, int HW, float eps, int img_u8, void* stream);
 /* conv1: whiten + 3x3 conv Cin=1 stride (2,1) pad 1 -> NHWC [B,H/2,W,C] + BN partial sums
  * colstats[B*H/2][2][C] (one row per output image row). w: [C][9] float32. */
-int htrvt_conv1_fwd(const float* img, const float* stats, const float* w, void* out, float* colstats,
-                    int B, int H, int W, int C, int dtype, void* stream);
+int htrvt_conv1_fwd(const void* img, const float* stats, const float* w, void* out, float* colstats,
+                    int B, int H, int W, int C, int dtype, int img_u8, void* stream);
 /* BN statistics from partial sums: train mode.  partial [rows][2][C]; count = #elements per channel.
  * Writes scale = gamma*rstd, shift = beta - mean*scale, saves mean/rstd, updates running stats
  * (momentum, unbiased running_var) when running_mean != NULL and adds 1 to *num_batches_tracked (int64, may be NULL). */
@@ -170,8 +173,8 @@ int htrvt_pool_tokens_bwd(const void* dtok, const void* x, const float* keep, vo
                           int dtype, void* stream);
 /* dW[C][9] += sum_pix dY * whitened-input tap (autograd of htrvt_conv1_fwd); partial: [blocks][C*9] float32 scratch */
 int htrvt_conv1_wgrad_blocks(int B, int H);
-int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, float* dw, float* partial,
-                      int B, int H, int W, int C, int dtype, void* stream);
+int htrvt_conv1_wgrad(const void* img, const float* stats, const void* dy, float* dw, float* partial,
+                      int B, int H, int W, int C, int dtype, int img_u8, void* stream);
 
 /* Backward of conv1 -> BatchNorm(train) -> ReLU -> max_pool2d(3,(2,1),1) (resnet18.py:74-77 under autograd) with
  * respect to conv1.weight [C][9], bn1.weight and bn1.bias, in one pass over the pooled gradient dpool [B,Hp,W,C] and
@@ -181,9 +184,9 @@ int htrvt_conv1_wgrad(const float* img, const float* stats, const void* dy, floa
  * htrvt_conv1_bwd_row_floats(C) floats.  dw, dgamma, dbeta accumulate. */
 int htrvt_conv1_bwd_rows(int B, int H);
 int htrvt_conv1_bwd_row_floats(int C);
-int htrvt_conv1_bwd(const float* img, const float* stats, const void* dpool, const uint8_t* idx, const float* w,
+int htrvt_conv1_bwd(const void* img, const float* stats, const void* dpool, const uint8_t* idx, const float* w,
                     const float* gamma, const float* mean, const float* rstd, float* partial, float* dw, float* dgamma,
-                    float* dbeta, int B, int H, int W, int C, int dtype, void* stream);
+                    float* dbeta, int B, int H, int W, int C, int dtype, int img_u8, void* stream);
 
 /* ---- weight layout helpers ----------------------------------------------------- */
 /* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */

@@ -290,3 +290,32 @@ def test_odd_batch_and_non_power_of_two_width(dtype):
         worst = min(worst, cos)
         assert cos > (0.999 if dtype == torch.float32 else 0.8), (n, cos)
     print(dtype, "worst gradient cosine vs float64 oracle", worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_uint8_images_equal_their_float_conversion(dtype):
+    """uint8 grey levels handed to the model are read as value / 255 by the first kernels (image
+    statistics, conv1 forward, conv1 backward): results must be bit-identical to feeding the converted float image"""
+    import htrvt_amd
+    cfg = O.Config(80, (64, 512), embed_dim=64, depth=1, num_heads=2)
+    sd = O.init_state_dict(cfg, seed=17, randomize_affine=True)
+    _, targets, lengths = O.synthetic_batch(3, 64, 512, 80, cfg.num_patches, seed=2)
+    g = torch.Generator().manual_seed(5)
+    xu = torch.randint(0, 256, (3, 1, 64, 512), generator=g, dtype=torch.uint8)
+    xf = xu.float().div(255)                       # torchvision ToTensor
+    torch.manual_seed(4)
+    keep = O.span_mask(cfg.num_patches, 0.4, 8)
+    res = []
+    for x in (xu, xf):
+        for fuse in (True, False):
+            m = _model(cfg, sd, dtype=dtype).train()
+            m._engine(torch.device("cuda", 0)).fuse_conv1_backward = fuse
+            y = m(x.cuda(), keep_mask=keep)
+            htrvt_amd.ctc_loss(y, targets, lengths).backward()
+            res.append((y.detach().cpu(), {n: p.grad.cpu() for n, p in m.named_parameters() if p.grad is not None}))
+    for fuse in (0, 1):
+        (yu, gu), (yf, gf) = res[fuse], res[2 + fuse]
+        assert torch.equal(yu, yf)
+        for n in ("patch_embed.conv1.weight", "patch_embed.bn1.weight", "patch_embed.bn1.bias", "head.weight"):
+            a, b = gu[n], gf[n]
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), (n, fuse)   # float atomics reorder sums

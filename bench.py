@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU iterations (about 10 s of host work in total)")
     return ap.parse_args()
 
 

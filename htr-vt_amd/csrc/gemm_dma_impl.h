@@ -690,6 +690,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
   const bool loader = SPEC ? !consumer : true;
   const int lw = SPEC ? (wave - NWC) & 3 : wave;   // index among the DMA-issuing waves
   const int wm = (wave >> 1) % (BM / 64), wn = wave & 1;
+  if (SPEC && !consumer) __builtin_amdgcn_s_setprio(3);   // the loaders' issue latency is the critical path of every k-tile
 
   DmaLoader<BM, AL, GATHER, NWL> la;
   DmaLoader<BN, BL, 0, NWL> lb;

@@ -7,6 +7,14 @@ from .ema import ModelEma  # noqa: F401
 from .engine import Engine, ModelShape  # noqa: F401
 
 
+def mark_weights_dirty(model):
+    """Tell a model's engines that its parameters / buffers were rewritten through raw device pointers (htrvt_adamw,
+    htrvt_sam_first_step / _restore, htrvt_ema_update ...): such writes bump neither `_version` nor `data_ptr()`, which
+    is what the packed-weight cache keys on.  Every raw-pointer writer in this package calls this."""
+    for eng in getattr(model, "_engines", {}).values():
+        eng.weights_epoch += 1
+
+
 def create_model(nb_cls, img_size, **kwargs):
     from .model import HTR_VT
     return HTR_VT.create_model(nb_cls, img_size, **kwargs)

@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("lda", i64), ("ldb", i64), ("ldc", i64),
         ("batch", i32), ("batch_inner", i32),
         ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64),
-        ("split_k", i32),
+        ("split_k", i32), ("splitk_ws", vp),
         ("nB", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32), ("Co", i32),
         ("kh", i32), ("kw", i32), ("sh", i32), ("sw", i32), ("ph", i32), ("pw", i32), ("Cpad", i32),
         ("cls_h", i32), ("cls_w", i32),
@@ -47,7 +47,7 @@ PROTOTYPES = {
     "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, vp]),
+    "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, vp]),
     "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -58,7 +58,8 @@ PROTOTYPES = {
     "htrvt_layernorm_bwd_blocks": (i32, [i64]),
     "htrvt_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "htrvt_softmax_bwd_rows": (i32, [vp, vp, vp, i64, i32, f32, i32, vp]),
-    "htrvt_colsum": (i32, [vp, i64, i32, i64, vp, vp, i32, i32, vp]),
+    "htrvt_colsum_workspace_floats": (C.c_size_t, [i64, i32]),
+    "htrvt_colsum": (i32, [vp, i64, i32, i64, vp, vp, i32, i32, vp, vp]),
     "htrvt_rowsum_f32": (i32, [vp, i32, i32, vp, vp]),
     "htrvt_bn_bwd_blocks": (i32, [i64]),
     "htrvt_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -80,7 +81,7 @@ PROTOTYPES = {
     "htrvt_sam_restore": (i32, [vp, vp, i64, vp]),
     "htrvt_ema_update": (i32, [vp, i32, i64, f64, vp]),
     "htrvt_ctc_greedy_decode": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp]),
-    "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
     "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
 }

@@ -188,10 +188,10 @@ __global__ __launch_bounds__(NT) void softmax_bwd_rows_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, long long rows, int cols, long long ld,
                                                       float* __restrict__ out, const float* __restrict__ keep,
-                                                      int keep_mod) {
+                                                      int keep_mod, float* __restrict__ ws) {
   // block = 32 column chunks (16 B each) x 32 row lanes; a half-wave reads 512 contiguous bytes of one row and every
-  // thread keeps 4 row loads in flight.  Few, fat blocks on purpose: the per-block float atomics on one output
-  // address serialise at ~0.2 us each, so the row splits are capped at 64 by the launcher.
+  // thread keeps 4 row loads in flight.  Reproducible: with several row splits (gridDim.y > 1) every split stores its
+  // own row of partial sums in ws[split][cols]; rowsum_f32_kernel then adds the rows to `out` in split order.
   constexpr int CH = Vec16<T>::N, RL = 32;
   using Raw = decltype(Vec16<T>().raw);
   __shared__ float red[RL][32][CH];
@@ -230,7 +230,11 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, l
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < RL; ++k) t += red[k][c][j];
-      atomicAdd(&out[(blockIdx.x * 32 + c) * CH + j], t);
+      const int col = (blockIdx.x * 32 + c) * CH + j;
+      if (gridDim.y > 1)
+        ws[(long long)blockIdx.y * cols + col] = t;
+      else
+        out[col] += t;
     }
   }
 }
@@ -304,6 +308,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
   dgamma[c] += (float)s2;
   const double g = gamma[c], r = rstd[c], mu = mean[c];
   coef[c] = (float)(g * r);
+  if (count <= 0.f) {   // eval-mode BatchNorm: mean / rstd are constants (running statistics), dx = gamma * rstd * g
+    coef[C + c] = 0.f;
+    coef[2 * C + c] = 0.f;
+    return;
+  }
   coef[C + c] = (float)(-g * r * r * s2 / count);
   coef[2 * C + c] = (float)(-g * r * s1 / count + g * r * r * mu * s2 / count);
 }
@@ -543,13 +552,23 @@ __global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const void* __restrict_
       }
     }
   }
-  // reduce the ppb threads sharing a channel group: through global atomics on the block's partial row
+  // reduce the ppb threads sharing a channel group through LDS, one tap at a time, in a fixed order (reproducible)
   float* prow = partial + (long long)blockIdx.x * C * 9;
-  if ((int)threadIdx.x < nthr) {
+  float* red = rows;   // [nthr][CH] floats <= 8 KB (the launcher sizes the LDS for both uses)
 #pragma unroll
-    for (int j = 0; j < CH; ++j)
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if ((int)threadIdx.x < nthr) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(&prow[(cg * CH + j) * 9 + t], acc[j][t]);
+      for (int j = 0; j < CH; ++j) red[threadIdx.x * CH + j] = acc[j][t];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+      const int cv = c / CH, j = c - cv * CH;
+      float a = 0.f;
+      for (int k = 0; k < ppb; ++k) a += red[(k * cvec + cv) * CH + j];
+      prow[c * 9 + t] = a;
+    }
   }
 }
 
@@ -624,8 +643,11 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 
 // decoupled weight decay Adam over one flat float32 buffer (torch.optim.AdamW semantics)
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long long n4, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2s) {
+                                                   float* __restrict__ v, long long n4, float decay, float w1, float b2,
+                                                   float w2, float eps, float bc2s, float neg_step) {
+  // the statement order of torch.optim.AdamW's single-tensor step (torch/optim/adamw.py): p *= 1 - lr*wd;
+  // m.lerp_(g, 1 - beta1); v = v*beta2 + (1 - beta2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * m/denom.
+  // Scalars are formed in double on the host (Python floats are doubles) and rounded once.
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -636,11 +658,11 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
       const float gj = (&gg.x)[j];
       float& mj = (&mm.x)[j];
       float& vj = (&vv.x)[j];
-      pj *= (1.f - lr * wd);
-      mj = b1 * mj + (1.f - b1) * gj;
-      vj = b2 * vj + (1.f - b2) * gj * gj;
-      const float denom = sqrtf(vj) / bc2s + eps;
-      pj -= (lr / bc1) * (mj / denom);
+      pj = __fmul_rn(pj, decay);
+      mj = __fadd_rn(mj, __fmul_rn(w1, __fsub_rn(gj, mj)));
+      vj = __fadd_rn(__fmul_rn(vj, b2), __fmul_rn(__fmul_rn(w2, gj), gj));
+      const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vj), bc2s), eps);
+      pj = __fadd_rn(pj, __fmul_rn(neg_step, __fdiv_rn(mj, denom)));
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
@@ -705,17 +727,31 @@ extern "C" int htrvt_softmax_bwd_rows(const void* p, const float* dp, void* ds, 
   return check_launch("softmax_bwd_rows");
 }
 
+static int colsum_splits(int64_t rows) {
+  long long splits = rows / 128;         // >= 128 rows (4 per thread) per block
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  return (int)splits;
+}
+
+extern "C" size_t htrvt_colsum_workspace_floats(int64_t rows, int cols) {
+  const int s = colsum_splits(rows);
+  return s > 1 ? (size_t)s * cols : 0;
+}
+
 extern "C" int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, float* out, const float* keep, int keep_mod,
-                            int dtype, void* stream) {
+                            int dtype, float* workspace, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(cols % ch == 0 && ld % ch == 0, "htrvt_colsum: cols/ld must be multiples of %d", ch);
   const int gx = (cols / ch + 31) / 32;
-  long long splits = rows / 128;         // >= 128 rows (4 per thread) per block, at most 64 atomics per output
-  if (splits > 64) splits = 64;
-  if (splits < 1) splits = 1;
+  const int splits = colsum_splits(rows);
+  HTRVT_REQUIRE(splits == 1 || workspace != nullptr, "htrvt_colsum: %d rows need a workspace (htrvt_colsum_workspace_floats)",
+                (int)rows);
   dim3 grid(gx, (unsigned)splits);
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)rows,
-                                       cols, (long long)ld, out, keep, keep_mod > 0 ? keep_mod : 1));
+                                       cols, (long long)ld, out, keep, keep_mod > 0 ? keep_mod : 1, workspace));
+  if (splits > 1)
+    hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, workspace, splits, cols, out);
   return check_launch("colsum");
 }
 
@@ -735,6 +771,7 @@ extern "C" int htrvt_bn_bwd_reduce(const void* dy, const void* yact, const void*
                                    float* partial, int64_t npix, int C, int dtype, void* stream) {
   const int ch = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT, "htrvt_bn_bwd_reduce: C=%d unsupported", C);
+  HTRVT_REQUIRE(dy && x && mean && rstd && partial, "htrvt_bn_bwd_reduce: null dy / x / mean / rstd / partial");
   const int cvec = C / ch, nthr = (NT / cvec) * cvec;
   const size_t smem = (size_t)nthr * 2 * ch * 4;
   dim3 grid(htrvt_bn_bwd_blocks(npix));
@@ -746,6 +783,7 @@ extern "C" int htrvt_bn_bwd_reduce(const void* dy, const void* yact, const void*
 extern "C" int htrvt_bn_bwd_finalize(const float* partial, int rows, int C, float count, const float* gamma,
                                      const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef,
                                      void* stream) {
+  HTRVT_REQUIRE(partial && gamma && mean && rstd && dgamma && dbeta && coef, "htrvt_bn_bwd_finalize: null argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, rows, C, count,
                      gamma, mean, rstd, dgamma, dbeta, coef);
   return check_launch("bn_bwd_finalize");
@@ -797,10 +835,9 @@ extern "C" int htrvt_conv1_wgrad(const void* img, const float* stats, const void
   HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0, "htrvt_conv1_wgrad: C=%d unsupported", C);
   const int cvec = C / ch, nthr = (NT / cvec) * cvec;
   const int nblk = htrvt_conv1_wgrad_blocks(B, H);
-  const size_t smem = (size_t)3 * (W + 2) * 4;
+  size_t smem = (size_t)3 * (W + 2) * 4;
+  if (smem < (size_t)nthr * ch * 4) smem = (size_t)nthr * ch * 4;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblk * C * 9 * 4, st);
-  HTRVT_REQUIRE(e == hipSuccess, "htrvt_conv1_wgrad: memset failed: %s", hipGetErrorString(e));
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_wgrad_kernel<T>, dim3(nblk), dim3(NT), smem, st, img, stats, (const T*)dy,
                                        partial, B, H, W, C, nthr, img_u8));
   hipLaunchKernelGGL(rowsum_f32_kernel, dim3((C * 9 + NT - 1) / NT), dim3(NT), 0, st, partial, nblk, C * 9, dw);
@@ -831,12 +868,14 @@ extern "C" int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype,
   return check_launch("cast_f32");
 }
 
-extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, int step, void* stream) {
+extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                           double eps, double weight_decay, int step, void* stream) {
   HTRVT_REQUIRE(n % 4 == 0 && step >= 1, "htrvt_adamw: n must be a multiple of 4 and step >= 1");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long long)(n / 4), lr,
-                     beta1, beta2, eps, weight_decay, bc1, bc2s);
+  HTRVT_REQUIRE(p && g && m && v, "htrvt_adamw: null buffer");
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long long)(n / 4),
+                     (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)bc2s, (float)(-(lr / bc1)));
   return check_launch("adamw");
 }

@@ -218,6 +218,8 @@ extern "C" int htrvt_conv1_bwd(const void* img, const float* stats, const void* 
                                float* dgamma, float* dbeta, int B, int H, int W, int C, int dtype, int img_u8, void* stream) {
   const int CH = dtype == HTRVT_BF16 ? 8 : 4;
   HTRVT_REQUIRE(dtype == HTRVT_BF16 || dtype == HTRVT_F32, "conv1_bwd: bad dtype %d", dtype);
+  HTRVT_REQUIRE(img && stats && dpool && idx && w && gamma && mean && rstd && partial && dw && dgamma && dbeta,
+                "conv1_bwd: null argument (train-mode batch statistics are required)");
   HTRVT_REQUIRE(B > 0 && H >= 4 && H % 2 == 0 && W > 0 && C > 0 && C % CH == 0, "conv1_bwd: bad shape B=%d H=%d W=%d C=%d", B,
                 H, W, C);
   const int cvec = C / CH, cgw = pick_cgw(cvec);

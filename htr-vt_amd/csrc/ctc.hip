@@ -45,8 +45,14 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
   int* ext = reinterpret_cast<int*>(lse + T);       // [Smax]
   float* buf0 = reinterpret_cast<float*>(ext + Smax);
   float* buf1 = buf0 + Smax;
-  float* occ0 = buf1 + Smax;  // [C]
-  float* occ1 = occ0 + C;
+  // occupancy of every state at the current step, double buffered over t (one barrier per step), summed per class in a
+  // FIXED order after the barrier: the blank through per-wave sums, a label class by walking the list of its states
+  // (head / nxt, ascending s).  No LDS float atomics: the gradient is bitwise reproducible.
+  float* os0 = buf1 + Smax;   // [Smax]
+  float* os1 = os0 + Smax;    // [Smax]
+  int* nxt = reinterpret_cast<int*>(os1 + Smax);   // [Smax] next state with the same label, -1 at the end
+  int* head = nxt + Smax;     // [C] first state of every label class, -1 if the class does not occur
+  float* obw = reinterpret_cast<float*>(head + C);  // [2][NT/64] per-wave blank occupancy
   __shared__ float s_ll;
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
   float* A = ws + (long long)b * T * Smax;
 
   for (int s = tid; s < S; s += NT) ext[s] = (s & 1) ? lab[s >> 1] : 0;
-  for (int c = tid; c < 2 * C; c += NT) occ0[c] = 0.f;
+  for (int c = tid; c < C; c += NT) head[c] = -1;
   for (int t = wave; t < T; t += NT / 64) {  // log-sum-exp of every frame, one wave per frame
     float m = -INFINITY;
     for (int c = lane; c < C; c += 64) m = fmaxf(m, x[(long long)t * C + c]);
@@ -120,7 +126,16 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
     cur = tmp;
   }
   }
-  if (tid == 0) s_ll = lse2(prev[S - 1], S > 1 ? prev[S - 2] : -INFINITY);
+  if (tid == 0) {
+    s_ll = lse2(prev[S - 1], S > 1 ? prev[S - 2] : -INFINITY);
+    for (int s = S - 2; s >= 1; s -= 2) {   // label states, last to first: every class list ends up ascending in s
+      const int e = ext[s];
+      if (e > 0 && e < C) {
+        nxt[s] = head[e];
+        head[e] = s;
+      }
+    }
+  }
   __syncthreads();
   const float ll = s_ll;
   const bool feasible = ll != -INFINITY;
@@ -144,7 +159,8 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
     for (int t = T - 1; t >= 0; --t) {
       const float* xt = x + (long long)t * C;
       const float l = lse[t];
-      float* occ = (t & 1) ? occ1 : occ0;
+      float* os = (t & 1) ? os1 : os0;
+      float* ow = obw + (t & 1) * (NT / 64);
       const float xc = xn, ac = an, gc = gn;
       if (t > 0) {
         if (act) {
@@ -165,22 +181,27 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
         }
         cur[tid] = bt;
       }
-      // occupancy exp(alpha + beta - emission - ll): the blank states (every even s, half of all) would serialise on
-      // one LDS address, so each wave sums them first
+      // occupancy exp(alpha + beta - emission - ll): the blank states (every even s, half of all) are summed per wave
       float ob = 0.f;
       if (act) {
         const float ab = ac + cur[tid];
         const float o = ab != -INFINITY ? __expf(ab - (xc - l) - ll) : 0.f;
         if (e == 0) ob = o;
-        else if (o != 0.f) atomicAdd(&occ[e], o);
+        else os[tid] = o;
       }
       ob = wave_sum(ob);
-      if (lane == 0 && ob != 0.f) atomicAdd(&occ[0], ob);
+      if (lane == 0) ow[wave] = ob;
       __syncthreads();
       for (int c = tid; c < C; c += NT) {
         const float xv = c == tid ? gc : xt[c];
-        g[(long long)t * C + c] = (expf(xv - l) - occ[c]) * invB;
-        occ[c] = 0.f;
+        float oc = 0.f;
+        if (c == 0) {
+#pragma unroll
+          for (int w = 0; w < NT / 64; ++w) oc += ow[w];
+        } else {
+          for (int s2 = head[c]; s2 >= 0; s2 = nxt[s2]) oc += os[s2];
+        }
+        g[(long long)t * C + c] = (expf(xv - l) - oc) * invB;
       }
       float* tmp = prev;
       prev = cur;
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
   for (int t = T - 1; t >= 0; --t) {
     const float* xt = x + (long long)t * C;
     const float l = lse[t];
-    float* occ = (t & 1) ? occ1 : occ0;
+    float* os = (t & 1) ? os1 : os0;
     for (int s = tid; s < S; s += NT) {
       const int e = ext[s];
       float bt;
@@ -205,12 +226,19 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
       }
       cur[s] = bt;
       const float ab = A[(long long)t * Smax + s] + bt;
-      if (ab != -INFINITY) atomicAdd(&occ[e], expf(ab - (xt[e] - l) - ll));
+      os[s] = ab != -INFINITY ? expf(ab - (xt[e] - l) - ll) : 0.f;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += NT) {
-      g[(long long)t * C + c] = (expf(xt[c] - l) - occ[c]) * invB;
-      occ[c] = 0.f;
+    if (wave == NT / 64 - 1) {   // blank class: the even states, lane-strided partial sums + a shuffle tree (fixed order)
+      float ob = 0.f;
+      for (int s = 2 * lane; s < S; s += 128) ob += os[s];
+      ob = wave_sum(ob);
+      if (lane == 0) g[(long long)t * C] = (expf(xt[0] - l) - ob) * invB;
+    }
+    for (int c = tid + 1; c < C; c += NT) {
+      float oc = 0.f;
+      for (int s2 = head[c]; s2 >= 0; s2 = nxt[s2]) oc += os[s2];
+      g[(long long)t * C + c] = (expf(xt[c] - l) - oc) * invB;
     }
     float* tmp = prev;
     prev = cur;
@@ -229,7 +257,7 @@ extern "C" int htrvt_ctc_loss(const float* logits, const int32_t* targets, const
                               float grad_scale, void* stream) {
   HTRVT_REQUIRE(B > 0 && T > 0 && C > 0 && max_target_len >= 0, "htrvt_ctc_loss: bad shape");
   const int Smax = 2 * max_target_len + 1;
-  const size_t smem = (size_t)(T + 3 * Smax + 2 * C) * 4;
+  const size_t smem = (size_t)(T + 6 * Smax + C + 2 * (NT / 64)) * 4;
   HTRVT_REQUIRE(smem <= 60 * 1024, "htrvt_ctc_loss: T=%d / target length %d too large for LDS", T, max_target_len);
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, logits, targets, tgt_len, tgt_off, nll, grad,
                      workspace, T, C, Smax, grad_scale / (float)B);

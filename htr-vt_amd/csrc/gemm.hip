@@ -229,6 +229,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KParams p) {
   if (p.split_k > 1) {
     kbeg = z * p.kchunk;
     kend = min(p.K, kbeg + p.kchunk);
+    coff = (long long)z * p.slab_stride;
   } else {
     const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
     Ab += (zo * p.sA_o + zi * p.sA_i) * ET<T>::SZ;
@@ -314,6 +315,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KParams p) {
   gemm_epilogue<T, TM, TN, 2, BN, NTHREADS>(acc, p, Cb, coff, m0 + wm * TM * 32, n0 + wn * TN * 32, wm, n0, tile_m, lane, smem);
 }
 
+// Deterministic split-K, second launch: C[m][n] (+)= slab[0][m][n] + slab[1][m][n] + ... in ascending K order.
+__global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
+                                                                 long long ldc, int nsl, int accumulate) {
+  const long long mn = (long long)M * N;
+  const int n4 = N >> 2;   // N % 4 == 0 (checked by the launcher)
+  for (long long i = (long long)blockIdx.x * NTHREADS + threadIdx.x; i < (long long)M * n4; i += (long long)gridDim.x * NTHREADS) {
+    const int m = (int)(i / n4), c = (int)(i - (long long)m * n4);
+    const float4* src = reinterpret_cast<const float4*>(ws + (long long)m * N) + c;
+    float4 a = *src;
+    for (int z = 1; z < nsl; ++z) {
+      const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + z * mn);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* dst = C + (long long)m * ldc + 4 * c;
+    if (accumulate) {
+      dst[0] += a.x; dst[1] += a.y; dst[2] += a.z; dst[3] += a.w;
+    } else {
+      dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int AL, int BL, int GATHER>
 int launch(const KParams& p, int zdim, hipStream_t st) {
   constexpr int smem = 2 * (TileGeom<T, BM, AL>::BYTES + TileGeom<T, BN, BL>::BYTES);
@@ -378,6 +401,8 @@ extern "C" int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d) {
   return (d->M + bm - 1) / bm;
 }
 
+static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int zdim, hipStream_t st);
+
 extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   HTRVT_REQUIRE(d != nullptr, "htrvt_gemm: null descriptor");
   HTRVT_REQUIRE(d->dtype == HTRVT_F32 || d->dtype == HTRVT_BF16, "htrvt_gemm: bad dtype %d", d->dtype);
@@ -417,6 +442,8 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   HTRVT_REQUIRE(!(d->split_k > 1) || (d->accumulate && d->c_f32 && d->batch <= 1),
                 "htrvt_gemm: split_k needs accumulate=1, c_f32=1, batch<=1");
   HTRVT_REQUIRE(!d->accumulate || d->c_f32, "htrvt_gemm: accumulate needs c_f32");
+  HTRVT_REQUIRE(d->splitk_ws == nullptr || (d->N % 4 == 0 && (reinterpret_cast<unsigned long long>(d->splitk_ws) & 15) == 0),
+                "htrvt_gemm: splitk_ws needs N %% 4 == 0 and a 16-byte aligned workspace");
 
   int bm, bn;
   if (pick_tile(d, &bm, &bn)) return -1;
@@ -472,6 +499,29 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   const int zdim = p.split_k > 1 ? p.split_k : (d->batch > 1 ? d->batch : 1);
   HTRVT_REQUIRE((long long)p.tiles_m * p.tiles_n < (1ll << 31) && zdim < 65536, "htrvt_gemm: grid too large");
   hipStream_t st = (hipStream_t)stream;
+  p.slab_stride = 0;
+  if (p.split_k > 1 && d->splitk_ws != nullptr) {
+    // reproducible form: every K range owns a dense [M][N] slab, summed in K order by splitk_reduce_kernel below
+    p.C = reinterpret_cast<char*>(d->splitk_ws);
+    p.ldc = d->N;
+    p.accumulate = 0;
+    p.slab_stride = (long long)d->M * d->N;
+    const int rc = launch_main(d, p, bm, bn, zdim, st);
+    if (rc) return rc;
+    long long items = (long long)d->M * (d->N / 4);
+    int grid = (int)((items + NTHREADS - 1) / NTHREADS);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(NTHREADS), 0, st, d->splitk_ws, reinterpret_cast<float*>(d->C), d->M,
+                       d->N, (long long)d->ldc, p.split_k, d->accumulate);
+    return check_launch("splitk_reduce");
+  }
+  return launch_main(d, p, bm, bn, zdim, st);
+}
+
+// picks the kernel family (LDS-DMA bfloat16 tiles or the register-staged kernel) and launches it
+static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int zdim, hipStream_t st) {
+  const bool cls = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0;
+  const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   if (d->dtype == HTRVT_BF16 && d->tile != 1) {  // throughput path: LDS-DMA staged 256-row tiles (gemm_dma.hip)
     KParams q = p;
     const int r = gemm_dma_try_launch(d, q, zdim, st);

@@ -31,6 +31,7 @@ struct KParams {
   int batch_inner;
   long long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
   int split_k, kchunk;
+  long long slab_stride;      // split_k > 1: element offset of K range z's private output slab (0: all ranges share C)
   int nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
   float alpha;
   int act, c_f32, accumulate;

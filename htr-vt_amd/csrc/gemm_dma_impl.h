@@ -677,6 +677,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
   if (p.split_k > 1) {
     kbeg = z * p.kchunk;
     kend = min(p.K, kbeg + p.kchunk);
+    coff = (long long)z * p.slab_stride;
   } else {
     const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
     Ab += (zo * p.sA_o + zi * p.sA_i) * 2;

@@ -187,10 +187,11 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
-                                      float* scale, float* shift, int C) {
+                                      float* scale, float* shift, float* rstd, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  if (rstd != nullptr) rstd[c] = 1.0f / sqrtf(rv[c] + eps);
   scale[c] = sc;
   shift[c] = beta[c] - rm[c] * sc;
 }
@@ -414,9 +415,10 @@ extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float co
 }
 
 extern "C" int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                                    const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+                                    const float* running_var, float eps, float* scale, float* shift, float* rstd, int C,
+                                    void* stream) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta,
-                     running_mean, running_var, eps, scale, shift, C);
+                     running_mean, running_var, eps, scale, shift, rstd, C);
   return check_launch("bn_eval_coeffs");
 }
 

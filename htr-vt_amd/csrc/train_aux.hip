@@ -55,10 +55,11 @@ __global__ __launch_bounds__(NT) void sam_first_kernel(float* __restrict__ p, co
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
     reinterpret_cast<float4*>(old_p)[i] = pp;
-    pp.x += gg.x * scale;   // e_w = 1.0 * grad * scale, rounded, then added (sam.py:24-25): no fused multiply-add
-    pp.y += gg.y * scale;
-    pp.z += gg.z * scale;
-    pp.w += gg.w * scale;
+    // e_w = 1.0 * grad * scale, rounded, then added (sam.py:24-25): explicit round-to-nearest ops, never contracted to an FMA
+    pp.x = __fadd_rn(pp.x, __fmul_rn(gg.x, scale));
+    pp.y = __fadd_rn(pp.y, __fmul_rn(gg.y, scale));
+    pp.z = __fadd_rn(pp.z, __fmul_rn(gg.z, scale));
+    pp.w = __fadd_rn(pp.w, __fmul_rn(gg.w, scale));
     reinterpret_cast<float4*>(p)[i] = pp;
   }
 }

@@ -75,3 +75,6 @@ class ModelEma:
         _, table, count, max_numel = self._table
         with torch.no_grad():
             check(lib.htrvt_ema_update(table.data_ptr(), count, max_numel, float(cdecay), stream()), "ema_update")
+        # the launch wrote the averaged weights through raw pointers: drop the engines' packed / cast copies of them
+        from . import mark_weights_dirty
+        mark_weights_dirty(self.ema.module if self.ema_has_module else self.ema)

@@ -73,8 +73,12 @@ class Engine:
         self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
+        # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
+        # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
+        self.deterministic = dtype == torch.float32
         self._side, self._side_active = None, False
         self.saved = None
+        self._bn_train = True
         self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
 
     # ------------------------------------------------------------------ small helpers
@@ -199,6 +203,11 @@ class Engine:
                 best, best_t = s, t
         return best
 
+    def _splitk_ws(self, sk, Mo, No):
+        if sk <= 1 or not self.deterministic or No % 4:
+            return None
+        return self._empty(sk, Mo, No, dtype=torch.float32)
+
     # Weight gradients have no consumer inside backward: they run on a side stream, overlapping the
     # (HBM-bound) BatchNorm / LayerNorm backward passes and the tails of the dgrad GEMMs on the main stream.
     def _on_side(self, fn, *tensors):
@@ -226,10 +235,11 @@ class Engine:
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
         M, N = dy.shape
         K = x.shape[1]
+        sk = self._split_k(N, K, M)
         gemm(dy, x, dw, dtype=self.dtype, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
-             split_k=self._split_k(N, K, M), accumulate=True, c_f32=True)
+             split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, N, K))
         if dbias is not None:
-            check(lib.htrvt_colsum(ptr(dy), M, N, N, ptr(dbias), None, 1, self.dti, stream()), "colsum")
+            ops.colsum(dy, M, N, N, dbias, dti=self.dti)
 
     def conv_fwd(self, x, wf, g: ConvGeom, want_stats, bn=None, relu=False, residual=None):
         """bn = (scale, shift): eval-mode BatchNorm (running statistics) folded into the launch -- C = relu?(conv * scale +
@@ -284,13 +294,14 @@ class Engine:
         M = g.B * g.Ho * g.Wo
         cpi = cpad(g.Ci, self.dtype)
         packed = self._zeros(g.taps, cpi, g.Co)
+        sk = self._split_k(g.taps * cpi, g.Co, M, conv=True)
         gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
              a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
-             split_k=self._split_k(g.taps * cpi, g.Co, M, conv=True), accumulate=True, c_f32=True)
+             split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, g.taps * cpi, g.Co))
         check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
 
     # ------------------------------------------------------------------ BatchNorm pieces
-    def bn_coeffs(self, P, prefix, C, train, cs=None, rows=0, count=0):
+    def bn_coeffs(self, P, prefix, C, train, cs=None, rows=0, count=0, save=False):
         """returns (scale, shift, save_mean, save_rstd)"""
         scale, shift = self._empty(C, dtype=torch.float32), self._empty(C, dtype=torch.float32)
         if train:
@@ -300,10 +311,13 @@ class Engine:
                                         ptr(P[prefix + ".running_var"]), ptr(P[prefix + ".num_batches_tracked"]),
                                         ptr(scale), ptr(shift), ptr(mean), ptr(rstd), stream()), "bn_finalize")
             return scale, shift, mean, rstd
+        # eval mode (running statistics).  save: an eval-mode backward (frozen-BN fine-tuning, saliency) needs them as
+        # (mean, rstd); they are constants there, bn_backward_finish is told so through self._bn_train
+        rstd = self._empty(C, dtype=torch.float32) if save else None
         check(lib.htrvt_bn_eval_coeffs(ptr(P[prefix + ".weight"]), ptr(P[prefix + ".bias"]), ptr(P[prefix + ".running_mean"]),
-                                       ptr(P[prefix + ".running_var"]), BN_EPS, ptr(scale), ptr(shift), C, stream()),
+                                       ptr(P[prefix + ".running_var"]), BN_EPS, ptr(scale), ptr(shift), ptr(rstd), C, stream()),
               "bn_eval_coeffs")
-        return scale, shift, None, None
+        return scale, shift, (P[prefix + ".running_mean"] if save else None), rstd
 
     def bn_apply(self, x, scale, shift, relu, res=None, rscale=None, rshift=None):
         y = torch.empty_like(x)
@@ -332,9 +346,10 @@ class Engine:
         src = partial
         if rows > 64:   # two-level reduction of the partial rows
             red = self._zeros(2 * C)
-            check(lib.htrvt_colsum(ptr(partial), rows, 2 * C, 2 * C, ptr(red), None, 1, 0, stream()), "colsum")
+            ops.colsum(partial, rows, 2 * C, 2 * C, red, dti=0)
             src, rows = red, 1
-        check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, float(npix), ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
+        count = float(npix) if self._bn_train else -1.0      # eval mode: dx = gamma * rstd * g
+        check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, count, ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
                                         ptr(G[prefix + ".weight"]), ptr(G[prefix + ".bias"]), ptr(coef), stream()),
               "bn_bwd_finalize")
         dx = torch.empty_like(x)
@@ -361,10 +376,10 @@ class Engine:
         check(lib.htrvt_layernorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(partial),
                                       rows, D, self.dti, stream()), "layernorm_bwd")
         if dbeta.data_ptr() == dgamma.data_ptr() + 4 * D:   # weight and bias adjacent in the flat gradient buffer: one launch
-            check(lib.htrvt_colsum(ptr(partial), nblk, 2 * D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
+            ops.colsum(partial, nblk, 2 * D, 2 * D, dgamma, dti=0)
         else:
-            check(lib.htrvt_colsum(ptr(partial), nblk, D, 2 * D, ptr(dgamma), None, 1, 0, stream()), "colsum")
-            check(lib.htrvt_colsum(partial.data_ptr() + 4 * D, nblk, D, 2 * D, ptr(dbeta), None, 1, 0, stream()), "colsum")
+            ops.colsum(partial, nblk, D, 2 * D, dgamma, dti=0)
+            ops.colsum(partial.data_ptr() + 4 * D, nblk, D, 2 * D, dbeta, dti=0)
         return dx
 
     # ------------------------------------------------------------------ forward
@@ -391,7 +406,7 @@ class Engine:
         cs = self._empty(B * (H // 2) + 64, 2, C1, dtype=torch.float32) if train else self._empty(B * (H // 2), 2, C1, dtype=torch.float32)
         w1 = P["patch_embed.conv1.weight"]
         check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, u8, st), "conv1_fwd")
-        sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W)
+        sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W, save=save)
         Hp = (H // 2 - 1) // 2 + 1
         a = self._empty(B, Hp, W, C1)
         idx = torch.empty(B, Hp, W, C1, dtype=torch.uint8, device=self.dev) if save else None
@@ -429,15 +444,15 @@ class Engine:
                     Hc, Wc, Cin = g1.Ho, g1.Wo, planes
                     continue
                 ca, cs1, r1 = self.conv_fwd(x, wf1, g1, train)
-                bn_a = self.bn_coeffs(P, p + ".bn1", planes, train, cs1, r1, B * g1.Ho * g1.Wo)
+                bn_a = self.bn_coeffs(P, p + ".bn1", planes, train, cs1, r1, B * g1.Ho * g1.Wo, save=save)
                 a1 = self.bn_apply(ca, bn_a[0], bn_a[1], relu=True)
                 cb, cs2, r2 = self.conv_fwd(a1, wf2, g2, train)
-                bn_b = self.bn_coeffs(P, p + ".bn2", planes, train, cs2, r2, B * g2.Ho * g2.Wo)
+                bn_b = self.bn_coeffs(P, p + ".bn2", planes, train, cs2, r2, B * g2.Ho * g2.Wo, save=save)
                 if bi == 0:
                     gd = ConvGeom(B, Hc, Wc, Cin, planes, 1, strd, 0)
                     wfd, _ = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
                     cd, csd, rd = self.conv_fwd(x, wfd, gd, train)
-                    bn_d = self.bn_coeffs(P, p + ".downsample.1", planes, train, csd, rd, B * gd.Ho * gd.Wo)
+                    bn_d = self.bn_coeffs(P, p + ".downsample.1", planes, train, csd, rd, B * gd.Ho * gd.Wo, save=save)
                     out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, res=cd, rscale=bn_d[0], rshift=bn_d[1])
                 else:
                     gd, cd, bn_d = None, None, None
@@ -502,7 +517,7 @@ class Engine:
         sstats = self._empty(B, 2, dtype=torch.float32)
         check(lib.htrvt_seq_whiten_fwd(ptr(raw), ptr(y), ptr(sstats), B, N * s.nb_cls, WHITEN_EPS, 0, st), "seq_whiten_fwd")
         if save:
-            sv.update(enc=enc_saved, x_last=xt, xn=xn, mn=mn, rn=rn, y=y, sstats=sstats, B=B, N=N)
+            sv.update(enc=enc_saved, x_last=xt, xn=xn, mn=mn, rn=rn, y=y, sstats=sstats, B=B, N=N, train=train)
             self.saved = sv
         return y
 
@@ -521,6 +536,7 @@ class Engine:
         scale = hd ** -0.5
         dy = dy.contiguous()
         self._zarena_begin()
+        self._bn_train = bool(sv["train"])
         assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
         self._side_active = self.overlap_wgrad
 
@@ -589,7 +605,7 @@ class Engine:
         # token assembly
         keep = sv["keep"]
         if keep is not None:
-            check(lib.htrvt_colsum(ptr(dx), M, D, D, ptr(G["mask_token"]), ptr(keep), N, self.dti, st), "colsum(mask_token)")
+            ops.colsum(dx, M, D, D, G["mask_token"], dti=self.dti, keep=keep, keep_mod=N)
         Bq, Hc, Wc = sv["l3_shape"]
         dfeat = self._empty(Bq, Hc, Wc, D)
         check(lib.htrvt_pool_tokens_bwd(ptr(dx), ptr(sv["l3"]), ptr(keep), ptr(dfeat), B, Hc, N, D, self.dti, st),
@@ -675,7 +691,7 @@ class Engine:
         u8 = 1 if img.dtype == torch.uint8 else 0
         sc, sf, mean, rstd = sv["bn1"]
         _, Hh, W, C1 = c1.shape
-        if self.fuse_conv1_backward:
+        if self.fuse_conv1_backward and self._bn_train:
             # Cin = 1: dW1, dgamma, dbeta from per-channel sums over the pooled gradient (csrc/conv1_bwd.hip)
             partial = self._empty(lib.htrvt_conv1_bwd_rows(B, 2 * Hh), lib.htrvt_conv1_bwd_row_floats(C1), dtype=torch.float32)
             check(lib.htrvt_conv1_bwd(ptr(img), ptr(sv["stats"]), ptr(dout), ptr(sv["idx"]), ptr(P["patch_embed.conv1.weight"]),

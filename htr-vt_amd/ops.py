@@ -67,7 +67,7 @@ class ConvGeom:
 def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
          Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
          accumulate=False, bias=None, colscale=None, preact=None, residual=None, colstats=None, tile=0,
-         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0):
+         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0, splitk_ws=None):
     """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
     is used); *_off are element offsets into them."""
     d = GemmDesc()
@@ -80,6 +80,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.sB_o, d.sB_i = sB
     d.sC_o, d.sC_i = sC
     d.split_k = split_k
+    d.splitk_ws = ptr(splitk_ws)    # float32 [split_k][M][N]: reproducible split-K (ordered slab sum, no atomics)
     d.cls_h, d.cls_w = (-1, -1) if cls is None else cls
     if geom is not None:
         geom.fill(d)
@@ -120,6 +121,16 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1))
     PROFILE.setdefault(key, {"flops": flops, "events": []})["events"].append((e0, e1))
     return d
+
+
+def colsum(x, rows, cols, ld, out, *, dti, keep=None, keep_mod=1):
+    """out[c] += sum_r x[r*ld + c] (reproducible two-stage sum); x / out may be tensors or raw device addresses"""
+    nws = lib.htrvt_colsum_workspace_floats(rows, cols)
+    dev = out.device if isinstance(out, torch.Tensor) else x.device
+    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+    xp = x if isinstance(x, int) else ptr(x)
+    op = out if isinstance(out, int) else ptr(out)
+    check(lib.htrvt_colsum(xp, rows, cols, ld, op, ptr(keep), keep_mod, dti, ptr(ws), stream()), "colsum")
 
 
 PROFILE = None   # dict while bench.py measures per-kernel durations, else None

@@ -20,6 +20,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from . import mark_weights_dirty
+
 
 class FlatParams:
     """Flat float32 parameter / gradient storage + the two gradient buckets.  Device-agnostic (the
@@ -117,6 +119,7 @@ class Trainer:
         gradient buffer.  Returns the local mean loss (device scalar)."""
         from .ctc import ctc_forward_backward, stage_targets
         eng, fl = self.engine, self.flat
+        fl.check_views()     # a caller that re-bound p.data (reference SAM.second_step, model.to()) must rebuild the Trainer
         staged = stage_targets(targets, lengths, img.device)   # before the forward is enqueued (see stage_targets)
         fl.flat_g.zero_()
         y = eng.forward(self.P, img, keep_mask=keep_mask, train=True, save=True)
@@ -134,18 +137,16 @@ class Trainer:
                               float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
                               self.step_count, stream()), "adamw")
         # the kernel wrote through raw pointers (no autograd version bump): invalidate the packed-weight cache
-        self.engine.weights_epoch += 1
+        mark_weights_dirty(self.model)
 
     def step(self, img, targets, lengths, keep_mask=None, lr=None):
         loss = self.forward_backward(img, targets, lengths, keep_mask)
         self.optimizer_step(lr)
         return loss
 
-    def sam_step(self, img, targets, lengths, keep_mask=None, keep_mask2=None, lr=None, rho=0.05):
-        """One iteration of the reference's optimizer, SAM(AdamW) (train.py:119-126, utils/sam.py:15-38, adaptive=False):
-        gradients at w -> climb to w + rho g/|g| -> gradients there (a second, independently masked pass) -> back to w
-        -> AdamW with the second gradients.  Three flat launches around the two forward/backward passes; under data
-        parallelism both passes all-reduce, so every rank computes the same norm.  Returns the first-pass loss."""
+    def sam_first_step(self, rho=0.05):
+        """SAM.first_step (utils/sam.py:15-27, adaptive=False) on the flat buffers: |g| by a two-stage reproducible sum,
+        old_w = w, w += rho g / (|g| + 1e-12).  Two launches."""
         from ._lib import check, lib
         from .ops import ptr, stream
         fl = self.flat
@@ -154,12 +155,27 @@ class Trainer:
             self._sam_buf = (torch.empty_like(fl.flat_p), torch.empty(lib.htrvt_sumsq_blocks(n), device=fl.flat_p.device),
                              torch.empty(1, device=fl.flat_p.device))
         old_p, partial, norm_sq = self._sam_buf
-        loss = self.forward_backward(img, targets, lengths, keep_mask)
         check(lib.htrvt_sumsq(ptr(fl.flat_g), n, ptr(partial), ptr(norm_sq), stream()), "sumsq")
         check(lib.htrvt_sam_first_step(ptr(fl.flat_p), ptr(fl.flat_g), ptr(old_p), n, float(rho), ptr(norm_sq), stream()),
               "sam_first_step")
-        self.engine.weights_epoch += 1
-        self.forward_backward(img, targets, lengths, keep_mask2)
-        check(lib.htrvt_sam_restore(ptr(fl.flat_p), ptr(old_p), n, stream()), "sam_restore")
+        mark_weights_dirty(self.model)
+
+    def sam_second_step(self, lr=None):
+        """SAM.second_step (utils/sam.py:29-38): w = old_w, then the base optimizer (AdamW) with the gradients taken at
+        the perturbed point."""
+        from ._lib import check, lib
+        from .ops import ptr, stream
+        fl = self.flat
+        check(lib.htrvt_sam_restore(ptr(fl.flat_p), ptr(self._sam_buf[0]), fl.flat_p.numel(), stream()), "sam_restore")
         self.optimizer_step(lr)
+
+    def sam_step(self, img, targets, lengths, keep_mask=None, keep_mask2=None, lr=None, rho=0.05):
+        """One iteration of the reference's optimizer, SAM(AdamW) (train.py:119-126, utils/sam.py:15-38, adaptive=False):
+        gradients at w -> climb to w + rho g/|g| -> gradients there (a second, independently masked pass) -> back to w
+        -> AdamW with the second gradients.  Three flat launches around the two forward/backward passes; under data
+        parallelism both passes all-reduce, so every rank computes the same norm.  Returns the first-pass loss."""
+        loss = self.forward_backward(img, targets, lengths, keep_mask)
+        self.sam_first_step(rho)
+        self.forward_backward(img, targets, lengths, keep_mask2)
+        self.sam_second_step(lr)
         return loss

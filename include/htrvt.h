@@ -54,6 +54,10 @@ typedef struct HtrvtGemmDesc {
   int32_t batch, batch_inner; /* batch index z -> (z / batch_inner, z % batch_inner) */
   int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i; /* batch strides in elements          */
   int32_t split_k;          /* >1: grid.z splits K, result accumulated (needs accumulate=1, c_f32=1) */
+  /* split_k > 1 only.  NULL: the K ranges meet in C through float atomics (summation order = arrival order).
+   * Non-NULL: float32 scratch of split_k*M*N elements; every K range stores its own [M][N] slab with plain stores and a
+   * second launch adds the slabs into C in ascending K order -- bitwise reproducible (the float32 parity path). */
+  float* splitk_ws;
   /* conv geometry (gather != 0) */
   int32_t nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
   /* HTRVT_GATHER_CONV_DGRAD of a strided conv, one launch per input-pixel parity class (bfloat16 only):
@@ -108,9 +112,9 @@ int htrvt_conv1_fwd(const void* img, const float* stats, const float* w, void* o
 int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
-/* eval mode: scale/shift from running stats */
+/* eval mode: scale/shift from running stats; rstd (may be NULL) = 1/sqrt(running_var + eps) for an eval-mode backward */
 int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                         float eps, float* scale, float* shift, int C, void* stream);
+                         float eps, float* scale, float* shift, float* rstd, int C, void* stream);
 /* y = [relu]( x*scale+shift [+ (res*rscale+rshift | res)] ), NHWC, any number of pixels */
 int htrvt_bn_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
                    const float* rshift, void* y, int64_t npix, int C, int relu, int dtype, void* stream);
@@ -153,14 +157,18 @@ int htrvt_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
 /* dS = scale * P * (dP - rowsum(dP*P)) ; P, dS of type dtype, dP float32 */
 int htrvt_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int n, float scale, int dtype,
                            void* stream);
-/* out[c] += sum_r x[r*ld + c]; rows with keep[r % keep_mod] != 0 are skipped when keep != NULL */
+/* out[c] += sum_r x[r*ld + c]; rows with keep[r % keep_mod] != 0 are skipped when keep != NULL.  Reproducible
+ * two-stage sum (no float atomics): workspace = htrvt_colsum_workspace_floats(rows, cols) floats (may be 0 -> NULL). */
+size_t htrvt_colsum_workspace_floats(int64_t rows, int cols);
 int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, float* out, const float* keep, int keep_mod,
-                 int dtype, void* stream);
+                 int dtype, float* workspace, void* stream);
 int htrvt_rowsum_f32(const float* partial, int rows, int cols, float* out, void* stream);
 /* train-mode BatchNorm backward (resnet18.py:27-37 under autograd): g = dy * (yact > 0) when yact != NULL */
 int htrvt_bn_bwd_blocks(int64_t npix);
 int htrvt_bn_bwd_reduce(const void* dy, const void* yact, const void* x, const float* mean, const float* rstd,
                         float* partial, int64_t npix, int C, int dtype, void* stream);
+/* count = elements per channel (train mode: batch statistics).  count <= 0: eval-mode BatchNorm, mean / rstd are the
+ * running statistics (constants): same dgamma / dbeta, dx = gamma * rstd * g. */
 int htrvt_bn_bwd_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* mean,
                           const float* rstd, float* dgamma, float* dbeta, float* coef /* [3][C] */, void* stream);
 int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* x, const float* coef, void* dx, void* gout,
@@ -197,8 +205,10 @@ int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, in
 int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 
 /* ---- optimizer step (train.py:94 AdamW(betas .9/.99, wd .5) as one flat launch) -- */
-int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                float eps, float weight_decay, int step, void* stream);
+/* Statement order and rounding points of torch.optim.AdamW's single-tensor step; the hyper-parameters are doubles as in
+ * Python, derived scalars (1 - lr*wd, 1 - beta, bias corrections, -lr/bc1) are formed in double and rounded once. */
+int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                double eps, double weight_decay, int step, void* stream);
 
 /* ---- around the path: SAM, EMA, greedy decode ---------------- */
 /* out[0] = sum x^2 (deterministic two-stage); partial: htrvt_sumsq_blocks(n) floats of scratch.  With x = the flat

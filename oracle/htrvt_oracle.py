@@ -436,13 +436,15 @@ def adamw_update(p, g, m, v, step, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay
 
 
 def sam_adamw_iteration(sd, cfg: Config, x, targets, target_lengths, keep1, keep2, opt_state, lr, rho=0.05,
-                        weight_decay=0.5):
+                        weight_decay=0.5, dtype=torch.float32):
     """One reference iteration (train.py:119-126 with utils/sam.py:15-38, adaptive=False) on a state_dict, in place:
     gradients at w -> w + rho g / (|g| + 1e-12) -> gradients there -> restore w -> AdamW with the second gradients.
     opt_state: {'step': int, 'm': {name: tensor}, 'v': {...}} (created empty on first use).
-    BatchNorm running statistics advance twice, exactly as two train-mode forwards do.  Returns the first-pass loss."""
+    BatchNorm running statistics advance twice, exactly as two train-mode forwards do.  Returns the first-pass loss.
+    dtype=torch.float64 (with a float64 state_dict) evaluates the same iteration in double: the rounding-free yardstick
+    for how far two float32 runs may legitimately drift apart (ReLU / arg-max flips under Adam's normalisation)."""
     def grads_at(keep):
-        loss, _, grads, stats = loss_and_grads(sd, cfg, x, targets, target_lengths, keep, train=True)
+        loss, _, grads, stats = loss_and_grads(sd, cfg, x, targets, target_lengths, keep, train=True, dtype=dtype)
         for k, (mean, var_unb) in stats.items():            # running-stat update of a train-mode forward
             sd[k + ".running_mean"].mul_(0.9).add_(mean, alpha=0.1)
             sd[k + ".running_var"].mul_(0.9).add_(var_unb, alpha=0.1)
@@ -450,7 +452,7 @@ def sam_adamw_iteration(sd, cfg: Config, x, targets, target_lengths, keep1, keep
         return loss, grads
 
     loss, g1 = grads_at(keep1)
-    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in g1.values())).float()
+    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in g1.values())).to(dtype)
     scale = rho / (norm + 1e-12)
     old = {k: sd[k].clone() for k in g1}
     for k, g in g1.items():

@@ -37,16 +37,16 @@ def test_pack_and_unpack_conv_weight(Co, Ci, taps, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_colsum(rows, cols, ld, dtype):
     lib, check, ptr, stream = _lib()
-    from htrvt_amd.ops import dt
+    from htrvt_amd.ops import colsum, dt
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randint(-3, 4, (rows, ld), generator=g).to(dtype).cuda()
     out = torch.full((cols,), 5.0, device="cuda")
-    check(lib.htrvt_colsum(ptr(x), rows, cols, ld, ptr(out), None, 0, dt(dtype), stream()), "colsum")
+    colsum(x, rows, cols, ld, out, dti=dt(dtype))
     assert torch.equal(out, 5.0 + x[:, :cols].float().sum(0))
     # row filter: only rows r with keep[r % N] == 0 contribute (gradient of the mask token)
     N = 16
     keep = (torch.arange(N) % 3 != 0).float().cuda()
     out2 = torch.zeros(cols, device="cuda")
-    check(lib.htrvt_colsum(ptr(x), rows, cols, ld, ptr(out2), ptr(keep), N, dt(dtype), stream()), "colsum(keep)")
+    colsum(x, rows, cols, ld, out2, dti=dt(dtype), keep=keep, keep_mod=N)
     sel = keep[torch.arange(rows, device="cuda") % N] == 0
     assert torch.equal(out2, x[sel][:, :cols].float().sum(0))

@@ -196,3 +196,122 @@ def test_conv_fwd_dgrad_wgrad_exact(dtype, cfg):
              a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi,
              split_k=3, accumulate=True, c_f32=True)
     assert torch.equal(dwp.double().cpu(), _pack_fwd(w.grad, cpi).permute(1, 2, 0))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# split-K: float atomics vs the reproducible slab form, explicit XCD-grouped factors (multiples of 8)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("split_k", [3, 8, 72])
+@pytest.mark.parametrize("slabs", [False, True])
+def test_conv_wgrad_splitk_exact(dtype, split_k, slabs):
+    """layer-1-like conv weight gradient (M = 9*192, N = 192, K = 9216 output pixels): split factors 8 and 72 take the
+    XCD-grouped block mapping of the LDS-DMA kernel (gemm_dma_impl.h), `slabs` the ordered two-launch reduction.
+    The result is added to a pre-filled C (accumulate)."""
+    ops = _ops()
+    Bn, Hi, Wi, Ci, Co, k, stride, pad = 2, 8, 576, 192, 192, 3, (1, 1), 1
+    x = _ints((Bn, Ci, Hi, Wi), -2, 3, seed=20).requires_grad_(False)
+    w = _ints((Co, Ci, k, k), -1, 2, seed=21).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    dy = _ints(tuple(y.shape), -2, 3, seed=22)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, k, stride, pad)
+    M = Bn * geom.Ho * geom.Wo
+    cpi = ops.cpad(Ci, dtype)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    base = _ints((geom.taps, cpi, Co), -5, 6, seed=23)
+    dwp = base.float().cuda()
+    ws = torch.empty(split_k, geom.taps * cpi, Co, dtype=torch.float32, device="cuda") if slabs else None
+    ops.gemm(xd, dyd, dwp, dtype=dtype, M=geom.taps * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co,
+             a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi,
+             split_k=split_k, accumulate=True, c_f32=True, splitk_ws=ws)
+    assert torch.equal(dwp.double().cpu(), base + _pack_fwd(w.grad, cpi).permute(1, 2, 0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("split_k", [4, 8, 64])
+def test_linear_wgrad_splitk_slabs_exact(dtype, split_k):
+    """dW[N][K] += dy^T x (TN, both operands MN-major) with the slab reduction, non-accumulating and accumulating"""
+    ops = _ops()
+    rows, N, K = 8192, 256, 192
+    dy, x = _ints((rows, N), -2, 3, seed=30), _ints((rows, K), -2, 3, seed=31)
+    ref = dy.t() @ x
+    for acc in (False, True):
+        c = torch.full((N, K), 3.0, dtype=torch.float32, device="cuda")
+        ws = torch.empty(split_k, N, K, dtype=torch.float32, device="cuda")
+        ops.gemm(dy.to(dtype).cuda(), x.to(dtype).cuda(), c, dtype=dtype, M=N, N=K, K=rows, lda=N, ldb=K, ldc=K,
+                 a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR, split_k=split_k, accumulate=True, c_f32=True, splitk_ws=ws)
+        assert torch.equal(c.double().cpu(), ref + 3.0), acc
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the conv-dgrad launch the training step spends most of its time in: backward-of-ReLU mask and BatchNorm-backward
+# column sums in the staged epilogue (Engine.conv_dgrad: one launch, or one per input-pixel parity class with
+# bnb_tile0 offsets for strided convolutions)
+# --------------------------------------------------------------------------------------------------------------------
+def _sparse_ints(shape, seed, p=0.25):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(-1, 2, shape, generator=g) * (torch.rand(shape, generator=g) < p)).double()
+
+
+FUSED_DGRAD = [  # B, Hi, Wi, Ci, Co, k, stride, pad
+    (2, 8, 256, 192, 192, 3, (1, 1), 1),     # layer-1 body: 16 full M tiles
+    (1, 5, 100, 192, 192, 3, (1, 1), 1),     # M = 500: tail tile
+    (2, 16, 128, 192, 192, 3, (2, 1), 1),    # layer1.0.conv1: 2 parity classes
+    (2, 8, 144, 192, 384, 3, (2, 2), 1),     # layer2.0.conv1: 4 parity classes, M per class = 576 (tail tile)
+    (2, 8, 144, 192, 384, 1, (2, 2), 0),     # downsample 1x1: three of the four classes receive no tap
+]
+
+
+@pytest.mark.parametrize("cfg", FUSED_DGRAD)
+@pytest.mark.parametrize("nbn", [1, 2])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
+    import htrvt_amd
+    from htrvt_amd.engine import Engine, ModelShape
+    ops = _ops()
+    dtype = torch.bfloat16
+    Bn, Hi, Wi, Ci, Co, k, stride, pad = cfg
+    eng = Engine(ModelShape(80, (64, 512), 64, 2, 2), dtype, "cuda")
+    geom = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, k, stride, pad)
+    # sparse +-1 operands keep |dx| far below 256, so the bf16 result and every float32 sum are exact integers
+    w = _sparse_ints((Co, Ci, k, k), 40)
+    dy = _sparse_ints((Bn, Co, geom.Ho, geom.Wo), 41)
+    dx = torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), w, dy, stride=stride, padding=pad).permute(0, 2, 3, 1)   # NHWC
+    res = _ints((Bn, Hi, Wi, Ci), -3, 4, seed=42)
+    relu_src = _ints((Bn, Hi, Wi, Ci), -1, 2, seed=43)            # a third of the elements pass
+    g_ref = (dx + (res if with_res else 0.0)) * (relu_src > 0)
+    assert g_ref.abs().max() < 256
+    gen = torch.Generator().manual_seed(44)
+    bnx = [_ints((Bn, Hi, Wi, Ci), -4, 5, seed=45 + t) for t in range(nbn)]
+    mean = [torch.randint(-2, 3, (Ci,), generator=gen).double() for _ in range(nbn)]
+    rstd = [torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (Ci,), generator=gen)].double() for _ in range(nbn)]
+
+    cpo = ops.cpad(Co, dtype)
+    wd = _pack_dgrad(w, cpo).to(dtype).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    rows = eng.dgrad_tiles(geom)
+    parts = [torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nbn)]
+    bnb = [(bnx[t].to(dtype).cuda(), mean[t].float().cuda(), rstd[t].float().cuda(), parts[t]) for t in range(nbn)]
+    out = eng.conv_dgrad(dyd, wd, geom, residual=res.to(dtype).cuda() if with_res else None,
+                         relu_src=relu_src.to(dtype).cuda(), bnb=bnb)
+    assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
+
+    # expected partial rows: 256-row M tiles of every launch, in launch order
+    sh, sw = stride
+    by_class = eng._dgrad_by_class(geom)
+    for t in range(nbn):
+        xhat = (bnx[t] - mean[t]) * rstd[t]
+        want = []
+        classes = [(a, b) for a in range(sh) for b in range(sw)] if by_class else [None]
+        for cl in classes:
+            gg = g_ref if cl is None else g_ref[:, cl[0]::sh, cl[1]::sw, :]
+            xx = xhat if cl is None else xhat[:, cl[0]::sh, cl[1]::sw, :]
+            gg, xx = gg.reshape(-1, Ci), xx.reshape(-1, Ci)
+            for r0 in range(0, gg.shape[0], 256):
+                want.append(torch.stack([gg[r0:r0 + 256].sum(0), (gg[r0:r0 + 256] * xx[r0:r0 + 256]).sum(0)]))
+        want = torch.stack(want)
+        got = parts[t].double().cpu()
+        assert got.shape == want.shape, (got.shape, want.shape)
+        assert torch.equal(got, want), (t, float((got - want).abs().max()))

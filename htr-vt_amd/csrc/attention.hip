@@ -1,0 +1,542 @@
+// attention.hip -- fused multi-head self-attention for the HTR-VT encoder block (bfloat16 throughput path, gfx950).
+//
+// Replaces, per transformer block and direction, the six launches and two [B*h,N,N] HBM round trips of
+//   attn = softmax(q @ k^T * scale); x = attn @ v                 (reference model_v1/model/HTR_VT.py:27-36, scale :17)
+// and of their autograd backward (train.py:123) by ONE launch each.  The scores S and probabilities P never leave the
+// CU: S tiles live in MFMA accumulators, P is rounded to bfloat16 in registers and fed straight back as an MFMA
+// operand (accumulator-as-operand k order), K / V (forward) and Q / dO (backward) tiles are staged through LDS.
+//
+// Layouts (what the qkv Linear writes, HTR_VT.py:29-30): qkv [B*N][3][h][hd] bfloat16, out / dout [B*N][h][hd].
+// lse2 [B][h][N] float32 = log2 of the softmax denominator in the scaled base-2 domain:
+//   P[q][k] = exp2(S[q][k] * scale * log2(e) - lse2[q]),   saved by the forward for the recomputing backward.
+//
+// CDNA4 mapping (forward; the backward kernels follow the same scheme with the roles of rows / lanes swapped):
+//   * workgroup = 4 waves = 128 queries of one (batch, head); two workgroups per CU (64 KB LDS, <= 256 VGPRs each).
+//   * "swapped" products: S^T = K Q^T and O^T = V^T P^T with v_mfma_f32_32x32x16_bf16, so a lane always owns ONE query
+//     (column of the accumulator tile): row max / row sum are 31 in-register ops + one cross-half exchange, the online
+//     softmax rescale is a per-lane scalar, and P^T (keys in the accumulator registers) is the B operand of the second
+//     product without any lane movement.
+//   * K is read by rows (ds_read_b128), V transposed (ds_read_b64_tr_b16); both tiles use one XOR-swizzled image that
+//     is conflict-free for both kinds of read (tools/lds_bank_check.py applies the banking rules to it).
+//   * K/V tiles (64 keys) are double buffered: global loads for tile t+1 are issued before the MFMAs of tile t and
+//     written to LDS after them (one barrier per tile).
+#include "gemm_common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int KT = 64;          // keys (forward, dQ role) or queries (dK/dV role) per staged tile
+constexpr float LOG2E = 1.44269504088896340736f;
+
+struct AttnParams {
+  const bf16_t* qkv;
+  bf16_t* out;         // forward output [B*N][h*hd]
+  float* lse2;         // [B*h][N]
+  const bf16_t* dout;  // backward: gradient of out
+  const bf16_t* o;     // backward: forward output
+  bf16_t* dqkv;        // backward: gradient of qkv
+  int B, N, h;
+  float sl2;           // scale * log2(e)
+  float scale;
+};
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [rows][HD] bfloat16 LDS tile
+template <int HD>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+  if constexpr (HD == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  else if constexpr (HD == 64) return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)));
+  else return 64 * row + 16 * (ch ^ ((row >> 2) & 3));
+}
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+
+// A operand (rows = 32 consecutive columns of the tile starting at 32*dt, k = 16 tile rows in accumulator-as-operand
+// order: element j of lane half h is tile row row0 + 16 s + 8 (j >> 2) + 4 h + (j & 3)) by two transposed reads
+template <int HD>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int s, int dt, int lane) {
+  const int h = lane >> 5, g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+  const int row = row0 + 16 * s + 4 * h + q;
+  const int c = 4 * dt + 2 * g + (p >> 1);
+  const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + lds_off<HD>(row, c) + 8 * (p & 1)));
+  const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + lds_off<HD>(row + 8, c) + 8 * (p & 1)));
+  const s16x8_t r = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// row operand: lane (r = lane & 31, h = lane >> 5) takes elements 16 s + 8 h .. + 7 of tile row row0 + r
+template <int HD>
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row0, int s, int lane) {
+  const uint4 v = *reinterpret_cast<const uint4*>(tile + lds_off<HD>(row0 + (lane & 31), 2 * s + (lane >> 5)));
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// registers 8 s .. 8 s + 7 of a 32x32 accumulator tile, rounded to bfloat16: the operand of a following MFMA that
+// contracts over the tile's ROW index
+__device__ __forceinline__ bf16x8_t acc_frag(const f32x16_t& x, int s) {
+  uint4 v;
+  v.x = pack_bf16x2(x[8 * s + 0], x[8 * s + 1]);
+  v.y = pack_bf16x2(x[8 * s + 2], x[8 * s + 3]);
+  v.z = pack_bf16x2(x[8 * s + 4], x[8 * s + 5]);
+  v.w = pack_bf16x2(x[8 * s + 6], x[8 * s + 7]);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// staging of one [KT][HD] tile: global -> registers (issue) ... registers -> LDS (commit), NTH threads.
+// Free functions over a caller-owned register array (as members of a struct the array stayed in scratch memory).
+template <int HD, int NTH>
+struct TileStage {
+  static constexpr int CPR = HD / 8;                 // 16-byte chunks per row
+  static constexpr int NL = KT * CPR / NTH;          // loads per thread
+  static_assert(KT * CPR % NTH == 0, "tile must divide over the threads");
+};
+
+template <int HD, int NTH, int NL>
+__device__ __forceinline__ void stage_issue(uint4 (&reg)[NL], const bf16_t* base, long long ld, int row0) {
+  constexpr int CPR = HD / 8;
+  static_assert(NL == TileStage<HD, NTH>::NL, "register array size");
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int c = threadIdx.x + NTH * u, row = c / CPR, ch = c - row * CPR;
+    reg[u] = *reinterpret_cast<const uint4*>(base + (long long)(row0 + row) * ld + ch * 8);
+  }
+}
+
+template <int HD, int NTH, int NL>
+__device__ __forceinline__ void stage_commit(const uint4 (&reg)[NL], char* tile) {
+  constexpr int CPR = HD / 8;
+  static_assert(NL == TileStage<HD, NTH>::NL, "register array size");
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int c = threadIdx.x + NTH * u, row = c / CPR, ch = c - row * CPR;
+    *reinterpret_cast<uint4*>(tile + lds_off<HD>(row, ch)) = reg[u];
+  }
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }   // the other 32-lane half's value
+
+// O[row][d] of a lane-per-row accumulator set: lane (r, hf) owns memory row `rowptr`, accumulator tile d register i is
+// column 32 d + (i & 3) + 8 (i >> 2) + 4 hf: four consecutive columns per register quad -> 8-byte stores
+template <int ND>
+__device__ __forceinline__ void store_lane_rows(const f32x16_t (&acc)[ND], bf16_t* rowptr, int hf, float mul) {
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 v;
+      v.x = pack_bf16x2(acc[d][4 * g + 0] * mul, acc[d][4 * g + 1] * mul);
+      v.y = pack_bf16x2(acc[d][4 * g + 2] * mul, acc[d][4 * g + 3] * mul);
+      *reinterpret_cast<uint2*>(rowptr + 32 * d + 8 * g + 4 * hf) = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int NTH = 256, QB = 128;
+  constexpr int TILE_B = KT * HD * 2;
+  constexpr int NS = HD / 16;       // k-steps of the QK^T product
+  constexpr int ND = HD / 32;       // 32-row tiles of O^T
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int nqb = p.N / QB;
+  const int total = gridDim.x;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);   // the query blocks of one head share an XCD (K/V in its L2)
+  const int bh = id / nqb, qb = id - bh * nqb;
+  const int b = bh / p.h, hh = bh - b * p.h;
+  const long long ld = 3ll * p.h * HD;
+  const bf16_t* qbase = p.qkv + (long long)b * p.N * ld + hh * HD;
+  const bf16_t* kbase = qbase + p.h * HD;
+  const bf16_t* vbase = kbase + p.h * HD;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hf = lane >> 5;
+  const int q0 = qb * QB + wave * 32;
+
+  // Q^T as the B operand of S^T = K Q^T: lane (r, hf) holds Q[q0 + r][16 s + 8 hf .. + 7]
+  bf16x8_t qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)(q0 + r) * ld + 16 * s + 8 * hf));
+
+  uint4 sk[TileStage<HD, NTH>::NL], sv[TileStage<HD, NTH>::NL];
+  stage_issue<HD, NTH>(sk, kbase, ld, 0);
+  stage_issue<HD, NTH>(sv, vbase, ld, 0);
+  stage_commit<HD, NTH>(sk, smem);
+  stage_commit<HD, NTH>(sv, smem + TILE_B);
+  __syncthreads();
+
+  f32x16_t o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = -INFINITY, l = 0.f;     // running max (scaled base-2 domain) and this lane half's share of the running sum
+
+  const int nt = p.N / KT;
+  for (int t = 0; t < nt; ++t) {
+    const char* kt = smem + (t & 1) * 2 * TILE_B;
+    const char* vt = kt + TILE_B;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+    // the last iteration re-stages its own tile into the idle buffer (nothing reads it): no conditional around the
+    // loads, so the staging registers stay registers
+    const int tn = min(t + 1, nt - 1);
+    stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
+    stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+    // S^T tiles: keys 32 c .. 32 c + 31 of this tile x the wave's 32 queries
+    f32x16_t st[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[c][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st[c], 0, 0, 0);
+    }
+    // online softmax for query r: this lane holds 32 of the tile's 64 keys, lane ^ 32 the other 32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        st[c][i] *= p.sl2;
+        mx = fmaxf(mx, st[c][i]);
+      }
+    mx = fmaxf(mx, xhalf(mx));
+    const float mn = fmaxf(m, mx);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float rs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        st[c][i] = exp2f(st[c][i] - mn);
+        rs += st[c][i];
+      }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8_t pb = acc_frag(st[c], s);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vt, 32 * c, s, d, lane), pb, o[d], 0, 0, 0);
+      }
+    stage_commit<HD, NTH>(sk, nxt);
+    stage_commit<HD, NTH>(sv, nxt + TILE_B);
+    __syncthreads();
+  }
+
+  l += xhalf(l);
+  const float inv = 1.0f / l;
+  store_lane_rows<ND>(o, p.out + ((long long)b * p.N + q0 + r) * ((long long)p.h * HD) + hh * HD, hf, inv);
+  if (hf == 0 && p.lse2 != nullptr) p.lse2[(long long)bh * p.N + q0 + r] = m + log2f(l);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// backward, first launch: dQ (and delta = rowsum(dO * O) for the second launch).  Same orientation as the forward: a
+// lane owns one query, K / V tiles stream through LDS, P is recomputed from the saved lse2.
+//   S^T = K Q^T ; P^T = exp2(S^T sl2 - lse2[q]) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta[q]) scale ; dQ^T += K^T dS^T
+// -------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p, float* __restrict__ delta) {
+  constexpr int NTH = 256, QB = 128;
+  constexpr int TILE_B = KT * HD * 2;
+  constexpr int NS = HD / 16, ND = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int nqb = p.N / QB;
+  const int total = gridDim.x;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int bh = id / nqb, qb = id - bh * nqb;
+  const int b = bh / p.h, hh = bh - b * p.h;
+  const long long ld = 3ll * p.h * HD, ldo = (long long)p.h * HD;
+  const bf16_t* qbase = p.qkv + (long long)b * p.N * ld + hh * HD;
+  const bf16_t* kbase = qbase + p.h * HD;
+  const bf16_t* vbase = kbase + p.h * HD;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hf = lane >> 5;
+  const int q0 = qb * QB + wave * 32;
+
+  bf16x8_t qf[NS], dof[NS];
+  float dl = 0.f;
+  {
+    const bf16_t* dorow = p.dout + ((long long)b * p.N + q0 + r) * ldo + hh * HD;
+    const bf16_t* orow = p.o + ((long long)b * p.N + q0 + r) * ldo + hh * HD;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)(q0 + r) * ld + 16 * s + 8 * hf));
+      Vec16<bf16_t> vd, vo;
+      vd.raw = *reinterpret_cast<const uint4*>(dorow + 16 * s + 8 * hf);
+      vo.raw = *reinterpret_cast<const uint4*>(orow + 16 * s + 8 * hf);
+      dof[s] = __builtin_bit_cast(bf16x8_t, vd.raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl = fmaf(vd.get(j), vo.get(j), dl);
+    }
+  }
+  dl += xhalf(dl);                                    // delta[q] = sum_d dO[q][d] O[q][d]
+  const float lse = p.lse2[(long long)bh * p.N + q0 + r];
+  if (hf == 0) delta[(long long)bh * p.N + q0 + r] = dl;
+
+  uint4 sk[TileStage<HD, NTH>::NL], sv[TileStage<HD, NTH>::NL];
+  stage_issue<HD, NTH>(sk, kbase, ld, 0);
+  stage_issue<HD, NTH>(sv, vbase, ld, 0);
+  stage_commit<HD, NTH>(sk, smem);
+  stage_commit<HD, NTH>(sv, smem + TILE_B);
+  __syncthreads();
+
+  f32x16_t dq[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+
+  const int nt = p.N / KT;
+  for (int t = 0; t < nt; ++t) {
+    const char* kt = smem + (t & 1) * 2 * TILE_B;
+    const char* vt = kt + TILE_B;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+    const int tn = min(t + 1, nt - 1);
+    stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
+    stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x16_t st, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vt, 32 * c, s, lane), dof[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pr = exp2f(fmaf(st[i], p.sl2, -lse));
+        st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8_t dsb = acc_frag(st, s);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kt, 32 * c, s, d, lane), dsb, dq[d], 0, 0, 0);
+      }
+    }
+    stage_commit<HD, NTH>(sk, nxt);
+    stage_commit<HD, NTH>(sv, nxt + TILE_B);
+    __syncthreads();
+  }
+  store_lane_rows<ND>(dq, p.dqkv + ((long long)b * p.N + q0 + r) * ld + hh * HD, hf, 1.0f);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// backward, second launch: dK and dV.  A lane owns one KEY (K / V fragments of the wave's 32 keys stay in registers),
+// Q / dO tiles stream through LDS (read by rows for S and dP, transposed for dV^T and dK^T), queries sit in the
+// accumulator rows, so the per-query constants lse2 / delta are per-register values read (broadcast) from LDS.
+//   S = Q K^T ; P = exp2(S sl2 - lse2[q]) ; dP = dO V^T ; dS = P (dP - delta[q]) scale ; dV^T += dO^T P ; dK^T += Q^T dS
+// One wave per SIMD (the two 32 x HD accumulator sets + the K / V fragments need > 256 registers).
+// -------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p, const float* __restrict__ delta) {
+  constexpr int NTH = 256, KB = 128;
+  constexpr int TILE_B = KT * HD * 2;
+  constexpr int STAGE_B = 2 * TILE_B + 2 * KT * 4;     // Q tile | dO tile | lse2[KT] | delta[KT]
+  constexpr int NS = HD / 16, ND = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nkb = p.N / KB;
+  const int total = gridDim.x;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int bh = id / nkb, kb = id - bh * nkb;
+  const int b = bh / p.h, hh = bh - b * p.h;
+  const long long ld = 3ll * p.h * HD, ldo = (long long)p.h * HD;
+  const bf16_t* qbase = p.qkv + (long long)b * p.N * ld + hh * HD;
+  const bf16_t* kbase = qbase + p.h * HD;
+  const bf16_t* vbase = kbase + p.h * HD;
+  const bf16_t* dobase = p.dout + (long long)b * p.N * ldo + hh * HD;
+  const float* lsebase = p.lse2 + (long long)bh * p.N;
+  const float* delbase = delta + (long long)bh * p.N;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hf = lane >> 5;
+  const int k0 = kb * KB + wave * 32;
+
+  bf16x8_t kf[NS], vf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    kf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
+    vf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
+  }
+
+  uint4 sq[TileStage<HD, NTH>::NL], sd[TileStage<HD, NTH>::NL];
+  float sc = 0.f;   // thread < 64: lse2 of query tid; 64 <= thread < 128: delta of query tid - 64
+  auto issue_consts = [&](int row0) {
+    if (threadIdx.x < 2 * KT) sc = threadIdx.x < KT ? lsebase[row0 + threadIdx.x] : delbase[row0 + threadIdx.x - KT];
+  };
+  auto commit_consts = [&](char* stage) {
+    if (threadIdx.x < 2 * KT) reinterpret_cast<float*>(stage + 2 * TILE_B)[threadIdx.x] = sc;
+  };
+  stage_issue<HD, NTH>(sq, qbase, ld, 0);
+  stage_issue<HD, NTH>(sd, dobase, ldo, 0);
+  issue_consts(0);
+  stage_commit<HD, NTH>(sq, smem);
+  stage_commit<HD, NTH>(sd, smem + TILE_B);
+  commit_consts(smem);
+  __syncthreads();
+
+  f32x16_t dk[ND], dv[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dk[d][i] = dv[d][i] = 0.f;
+
+  const int nt = p.N / KT;
+  for (int t = 0; t < nt; ++t) {
+    const char* qt = smem + (t & 1) * STAGE_B;
+    const char* dot = qt + TILE_B;
+    const float* cst = reinterpret_cast<const float*>(qt + 2 * TILE_B);
+    char* nxt = smem + ((t + 1) & 1) * STAGE_B;
+    const int tn = min(t + 1, nt - 1);
+    stage_issue<HD, NTH>(sq, qbase, ld, tn * KT);
+    stage_issue<HD, NTH>(sd, dobase, ldo, tn * KT);
+    issue_consts(tn * KT);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x16_t st, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qt, 32 * c, s, lane), kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dot, 32 * c, s, lane), vf[s], dp, 0, 0, 0);
+      }
+      // accumulator register i is query 32 c + (i & 3) + 8 (i >> 2) + 4 hf of the tile
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 ls = *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf);
+        const float4 de = *reinterpret_cast<const float4*>(cst + KT + 32 * c + 8 * g + 4 * hf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pr = exp2f(fmaf(st[4 * g + j], p.sl2, -(&ls.x)[j]));
+          st[4 * g + j] = pr;                                               // P
+          dp[4 * g + j] = pr * (dp[4 * g + j] - (&de.x)[j]) * p.scale;      // dS
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8_t pb = acc_frag(st, s), dsb = acc_frag(dp, s);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dot, 32 * c, s, d, lane), pb, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qt, 32 * c, s, d, lane), dsb, dk[d], 0, 0, 0);
+        }
+      }
+    }
+    stage_commit<HD, NTH>(sq, nxt);
+    stage_commit<HD, NTH>(sd, nxt + TILE_B);
+    commit_consts(nxt);
+    __syncthreads();
+  }
+  bf16_t* grow = p.dqkv + ((long long)b * p.N + k0 + r) * ld + hh * HD;
+  store_lane_rows<ND>(dk, grow + p.h * HD, hf, 1.0f);
+  store_lane_rows<ND>(dv, grow + 2 * p.h * HD, hf, 1.0f);
+}
+
+template <typename K>
+int set_lds(K kern, int smem, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, smem, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+template <int HD>
+int launch_fwd(const AttnParams& p, hipStream_t st) {
+  constexpr int smem = 2 * 2 * KT * HD * 2;
+  static bool attr_done = false;
+  auto kern = attn_fwd_kernel<HD>;
+  if (!attr_done) {
+    if (int rc = set_lds(kern, smem, "attn_fwd")) return rc;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.B * p.h * (p.N / 128)), dim3(256), smem, st, p);
+  return check_launch("attn_fwd");
+}
+
+template <int HD>
+int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
+  constexpr int smem_dq = 2 * 2 * KT * HD * 2;
+  constexpr int smem_kv = 2 * (2 * KT * HD * 2 + 2 * KT * 4);
+  static bool attr_done = false;
+  auto kq = attn_bwd_dq_kernel<HD>;
+  auto kkv = attn_bwd_dkv_kernel<HD>;
+  if (!attr_done) {
+    if (int rc = set_lds(kq, smem_dq, "attn_bwd_dq")) return rc;
+    if (int rc = set_lds(kkv, smem_kv, "attn_bwd_dkv")) return rc;
+    attr_done = true;
+  }
+  const dim3 grid(p.B * p.h * (p.N / 128));
+  hipLaunchKernelGGL(kq, grid, dim3(256), smem_dq, st, p, delta);
+  hipLaunchKernelGGL(kkv, grid, dim3(256), smem_kv, st, p, (const float*)delta);
+  return check_launch("attn_bwd");
+}
+
+}  // namespace
+
+extern "C" int htrvt_attn_supported(int N, int hd, int dtype) {
+  return dtype == HTRVT_BF16 && N >= 128 && N % 128 == 0 && (hd == 32 || hd == 64 || hd == 128);
+}
+
+extern "C" int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, int N, int heads, int hd, float scale, int dtype,
+                              void* stream) {
+  HTRVT_REQUIRE(qkv && out, "htrvt_attn_fwd: null operand");
+  HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
+                "htrvt_attn_fwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
+  HTRVT_REQUIRE((long long)B * N * 3 * heads * hd < (1ll << 31), "htrvt_attn_fwd: qkv too large");
+  AttnParams p{};
+  p.qkv = (const bf16_t*)qkv;
+  p.out = (bf16_t*)out;
+  p.lse2 = lse2;
+  p.B = B; p.N = N; p.h = heads;
+  p.scale = scale;
+  p.sl2 = scale * LOG2E;
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 128) return launch_fwd<128>(p, st);
+  if (hd == 64) return launch_fwd<64>(p, st);
+  return launch_fwd<32>(p, st);
+}
+
+extern "C" int htrvt_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, float* delta, void* dqkv,
+                              int B, int N, int heads, int hd, float scale, int dtype, void* stream) {
+  HTRVT_REQUIRE(qkv && out && dout && lse2 && delta && dqkv, "htrvt_attn_bwd: null operand");
+  HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
+                "htrvt_attn_bwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
+  AttnParams p{};
+  p.qkv = (const bf16_t*)qkv;
+  p.o = (const bf16_t*)out;
+  p.dout = (const bf16_t*)dout;
+  p.lse2 = const_cast<float*>(lse2);
+  p.dqkv = (bf16_t*)dqkv;
+  p.B = B; p.N = N; p.h = heads;
+  p.scale = scale;
+  p.sl2 = scale * LOG2E;
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 128) return launch_bwd<128>(p, delta, st);
+  if (hd == 64) return launch_bwd<64>(p, delta, st);
+  return launch_bwd<32>(p, delta, st);
+}

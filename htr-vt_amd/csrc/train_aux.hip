@@ -50,7 +50,8 @@ __global__ __launch_bounds__(NT) void sumsq_final_kernel(const float* __restrict
 // ------------------------------------------------------------------ SAM first step: old = w ; w += g * rho / (|g| + 1e-12)
 __global__ __launch_bounds__(NT) void sam_first_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ old_p,
                                                        long long n4, float rho, const float* __restrict__ norm_sq) {
-  const float scale = rho / (sqrtf(norm_sq[0]) + 1e-12f);
+  // scale = rho / (|g| + 1e-12) as torch evaluates `float / tensor` (Tensor.__rtruediv__): reciprocal, then multiply
+  const float scale = __fmul_rn(__frcp_rn(__fadd_rn(__fsqrt_rn(norm_sq[0]), 1e-12f)), rho);
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];

@@ -73,6 +73,7 @@ class Engine:
         self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
+        self.fused_attention = True    # bf16: one launch per direction, scores / probabilities never reach HBM (csrc/attention.hip)
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
@@ -486,15 +487,13 @@ class Engine:
             ln1, m1, r1 = self.ln_fwd(xt, P[p + ".norm1.weight"], P[p + ".norm1.bias"], save)
             wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
             qkv = self.linear_fwd(ln1, wq, P[p + ".attn.qkv.bias"])
-            S = self._empty(B * h, N, N, dtype=torch.float32)
-            gemm(qkv, qkv, S, dtype=self.dtype, M=N, N=N, K=hd, lda=3 * D, ldb=3 * D, ldc=N, batch=B * h, batch_inner=h,
-                 sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(h * N * N, N * N), b_off=D, alpha=scale, c_f32=True)
-            Pm = self._empty(B * h, N, N)
-            check(lib.htrvt_softmax_rows(ptr(S), ptr(Pm), B * h * N, N, self.dti, st), "softmax_rows")
-            del S
             O = self._empty(M, D)
-            gemm(Pm, qkv, O, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=D, b_layout=MNMAJOR, batch=B * h,
-                 batch_inner=h, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * D, hd), b_off=2 * D)
+            if self.fused_attention and lib.htrvt_attn_supported(N, hd, self.dti):
+                # bf16: one launch, scores / probabilities stay on chip; lse2 is what the recomputing backward needs
+                Pm, lse = None, (self._empty(B * h, N, dtype=torch.float32) if save else None)
+                check(lib.htrvt_attn_fwd(ptr(qkv), ptr(O), ptr(lse), B, N, h, hd, scale, self.dti, st), "attn_fwd")
+            else:
+                Pm, lse = self._attention_fwd_unfused(qkv, O, B, N, D, h, hd, scale, st), None
             wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
             x1 = self.linear_fwd(O, wp, P[p + ".attn.proj.bias"], residual=xt)
             ln2, m2, r2 = self.ln_fwd(x1, P[p + ".norm2.weight"], P[p + ".norm2.bias"], save)
@@ -504,7 +503,7 @@ class Engine:
             w2_ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
             x2 = self.linear_fwd(hact, w2_, P[p + ".mlp.fc2.bias"], residual=x1)
             if save:
-                enc_saved.append(dict(p=p, x0=xt, ln1=ln1, m1=m1, r1=r1, qkv=qkv, P=Pm, O=O, x1=x1, ln2=ln2, m2=m2, r2=r2,
+                enc_saved.append(dict(p=p, x0=xt, ln1=ln1, m1=m1, r1=r1, qkv=qkv, P=Pm, lse=lse, O=O, x1=x1, ln2=ln2, m2=m2, r2=r2,
                                       hpre=hpre, h=hact))
             xt = x2
 
@@ -520,6 +519,39 @@ class Engine:
             sv.update(enc=enc_saved, x_last=xt, xn=xn, mn=mn, rn=rn, y=y, sstats=sstats, B=B, N=N, train=train)
             self.saved = sv
         return y
+
+    def _attention_fwd_unfused(self, qkv, O, B, N, D, h, hd, scale, st):
+        """float32 path (and shapes the fused kernel does not serve): S = scale q k^T, row softmax, O = P v as batched
+        GEMMs over the [B,N,3,h,hd] layout; returns P (kept for the backward)"""
+        S = self._empty(B * h, N, N, dtype=torch.float32)
+        gemm(qkv, qkv, S, dtype=self.dtype, M=N, N=N, K=hd, lda=3 * D, ldb=3 * D, ldc=N, batch=B * h, batch_inner=h,
+             sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(h * N * N, N * N), b_off=D, alpha=scale, c_f32=True)
+        Pm = self._empty(B * h, N, N)
+        check(lib.htrvt_softmax_rows(ptr(S), ptr(Pm), B * h * N, N, self.dti, st), "softmax_rows")
+        del S
+        gemm(Pm, qkv, O, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=D, b_layout=MNMAJOR, batch=B * h,
+             batch_inner=h, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * D, hd), b_off=2 * D)
+        return Pm
+
+    def _attention_bwd_unfused(self, qkv, Pm, dO, dqkv, B, N, D, h, hd, scale, st):
+        """float32 path (and shapes the fused kernel does not serve): batched GEMMs + row-softmax backward over the saved P"""
+        bstr = dict(batch=B * h, batch_inner=h)
+        # dV = P^T dO
+        gemm(Pm, dO, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=D, ldc=3 * D, a_layout=MNMAJOR, b_layout=MNMAJOR,
+             sA=(h * N * N, N * N), sB=(N * D, hd), sC=(N * 3 * D, hd), c_off=2 * D, **bstr)
+        # dP = dO V^T
+        dP = self._empty(B * h, N, N, dtype=torch.float32)
+        gemm(dO, qkv, dP, dtype=self.dtype, M=N, N=N, K=hd, lda=D, ldb=3 * D, ldc=N, sA=(N * D, hd), sB=(N * 3 * D, hd),
+             sC=(h * N * N, N * N), b_off=2 * D, c_f32=True, **bstr)
+        dS = self._empty(B * h, N, N)
+        check(lib.htrvt_softmax_bwd_rows(ptr(Pm), ptr(dP), ptr(dS), B * h * N, N, scale, self.dti, st), "softmax_bwd_rows")
+        del dP
+        # dQ = dS K ; dK = dS^T Q
+        gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, b_layout=MNMAJOR,
+             sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=D, c_off=0, **bstr)
+        gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, a_layout=MNMAJOR,
+             b_layout=MNMAJOR, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=0, c_off=D, **bstr)
+        del dS
 
     # ------------------------------------------------------------------ backward
     def backward(self, P, G, dy, after_encoder=None, after_layer3=None):
@@ -575,23 +607,12 @@ class Engine:
             self.linear_wgrad(dx1, e["O"], G[p + ".attn.proj.weight"], G[p + ".attn.proj.bias"])
             qkv, Pm = e["qkv"], e["P"]
             dqkv = self._empty(M, 3 * D)
-            bstr = dict(batch=B * h, batch_inner=h)
-            # dV = P^T dO
-            gemm(Pm, dO, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=D, ldc=3 * D, a_layout=MNMAJOR, b_layout=MNMAJOR,
-                 sA=(h * N * N, N * N), sB=(N * D, hd), sC=(N * 3 * D, hd), c_off=2 * D, **bstr)
-            # dP = dO V^T
-            dP = self._empty(B * h, N, N, dtype=torch.float32)
-            gemm(dO, qkv, dP, dtype=self.dtype, M=N, N=N, K=hd, lda=D, ldb=3 * D, ldc=N, sA=(N * D, hd), sB=(N * 3 * D, hd),
-                 sC=(h * N * N, N * N), b_off=2 * D, c_f32=True, **bstr)
-            dS = self._empty(B * h, N, N)
-            check(lib.htrvt_softmax_bwd_rows(ptr(Pm), ptr(dP), ptr(dS), B * h * N, N, scale, self.dti, st), "softmax_bwd_rows")
-            del dP
-            # dQ = dS K ; dK = dS^T Q
-            gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, b_layout=MNMAJOR,
-                 sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=D, c_off=0, **bstr)
-            gemm(dS, qkv, dqkv, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=3 * D, a_layout=MNMAJOR,
-                 b_layout=MNMAJOR, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * 3 * D, hd), b_off=0, c_off=D, **bstr)
-            del dS
+            if Pm is None:      # fused forward: recomputing fused backward (dQ launch, then dK/dV launch)
+                delta = self._empty(B * h, N, dtype=torch.float32)
+                check(lib.htrvt_attn_bwd(ptr(qkv), ptr(e["O"]), ptr(dO), ptr(e["lse"]), ptr(delta), ptr(dqkv), B, N, h, hd,
+                                         scale, self.dti, st), "attn_bwd")
+            else:
+                self._attention_bwd_unfused(qkv, Pm, dO, dqkv, B, N, D, h, hd, scale, st)
             wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
             dln1 = self.linear_dgrad(dqkv, wq)
             self.linear_wgrad(dqkv, e["ln1"], G[p + ".attn.qkv.weight"], G[p + ".attn.qkv.bias"])

@@ -131,6 +131,18 @@ int htrvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
                         int64_t rows, int D, float eps, int dtype, void* stream);
 /* in-place row softmax of float32 scores [rows][n] -> probabilities of type dtype in `p` */
 int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, void* stream);
+/* Fused multi-head self-attention, bfloat16 (HTR_VT.py:27-36: softmax(q k^T * scale) v and its autograd backward).
+ * qkv [B*N][3][heads][hd] (the qkv Linear's output), out / dout [B*N][heads][hd], dqkv like qkv; scores and
+ * probabilities stay on chip.  lse2 [B*heads][N] float32 (may be NULL in the forward when no backward follows):
+ * log2 of the softmax denominator in the scaled base-2 domain, P = exp2(S * scale * log2(e) - lse2).
+ * delta [B*heads][N] float32: scratch of the backward (rowsum(dout * out), written by its first launch).
+ * htrvt_attn_supported: N a multiple of 128, hd in {32, 64, 128}, dtype bfloat16 (others: the htrvt_gemm +
+ * htrvt_softmax_rows path). */
+int htrvt_attn_supported(int N, int hd, int dtype);
+int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, int N, int heads, int hd, float scale, int dtype,
+                   void* stream);
+int htrvt_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, float* delta, void* dqkv,
+                   int B, int N, int heads, int hd, float scale, int dtype, void* stream);
 /* param-free LN over all N*C logits of a sample (HTR_VT.py:136,239): in dtype -> out float32 */
 int htrvt_seq_whiten_fwd(const void* x, float* y, float* stats, int B, int NC, float eps, int dtype, void* stream);
 

@@ -6,6 +6,8 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher: spawns the N rank processes itself (before any GPU call)
+    python bench.py --gpus N --scaling strong   # global batch 128 split over the ranks (default: weak, 128 per GPU)
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     -- the dominant MFMA kernel: algorithmic FLOPs / HIP-event duration, measured live
@@ -31,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (weak scaling) / in total (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU; strong: --batch images in total, split evenly over the ranks")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
@@ -88,12 +92,35 @@ def cpu_baseline(args, mask):
                       f", torch CPU float32, {cores} threads"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.  This process has made no
+    HIP call yet and never will (it only waits), each rank is a fresh interpreter with the torch.distributed.run
+    environment variables; rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = p_.wait() or rc
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ      # under torch.distributed.run the RCCL path runs even at N=1
@@ -112,6 +139,9 @@ def main():
     model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=dtype).to(dev)
     N = model.num_patches
     B = args.batch
+    if args.scaling == "strong":
+        assert args.batch % world == 0, f"strong scaling: --batch {args.batch} must divide over {world} ranks"
+        B = args.batch // world
     x, tg, tl = synthetic_batch(B, 64, args.width, 80, N, seed=rank)
     x = x.to(dev)
     torch.manual_seed(7)
@@ -182,41 +212,54 @@ def main():
         tr.engine.overlap_wgrad = saved_overlap
     if rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
-        rows = []
+        rows, by_sym = [], {}
         for key, ent in prof.items():
             ts = [a.elapsed_time(b) for a, b in ent["events"]]
-            rows.append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2))
+            rows.append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2, ent["kernel"]))
+            sym = by_sym.setdefault(ent["kernel"], {"ms": 0.0, "flops": 0.0, "n": 0, "shapes": []})
+            sym["ms"] += sum(ts)
+            sym["flops"] += ent["flops"] * len(ts)
+            sym["n"] += len(ts)
+            sym["shapes"].append((sum(ts), key, ent["flops"], sum(ts) / len(ts), len(ts) // 2))
         rows.sort(reverse=True)
-        tot, key, flops, avg_ms, per_step = rows[0]
         names = {0: "plain", 1: "conv-fwd", 2: "conv-dgrad", 3: "conv-wgrad"}
         if args.gemm_table:
             with open(args.gemm_table, "w") as f:
-                f.write("ms/step  avg_us  n/step  TFLOP/s  dtype,aL,bL,gather,M,N,K,batch,...\n")
-                for t_, k_, fl_, av_, n_ in rows:
-                    f.write(f"{t_ / 2:7.3f} {av_ * 1e3:8.1f} {n_:4d} {fl_ / (av_ * 1e-3) / 1e12:8.1f}  {k_}\n")
+                f.write("ms/step  avg_us  n/step  TFLOP/s  kernel | dtype,aL,bL,gather,M,N,K,batch\n")
+                for t_, k_, fl_, av_, n_, sy_ in rows:
+                    f.write(f"{t_ / 2:7.3f} {av_ * 1e3:8.1f} {n_:4d} {fl_ / (av_ * 1e-3) / 1e12:8.1f}  {sy_} | {k_}\n")
+        # dominant kernel = the rocprofv3 SYMBOL with the largest time share (one symbol serves several launch shapes);
+        # achieved = its algorithmic FLOPs per launch / its average launch duration, both averaged over all its launches
+        # of a step, which is what the `rocprofv3 --kernel-trace --stats` row of that symbol averages too
+        symname, sym = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = sym["ms"] / sym["n"]
+        flops = sym["flops"] / sym["n"]
+        per_step = sym["n"] // 2
         achieved = flops / (avg_ms * 1e-3) / 1e12
+        sym["shapes"].sort(reverse=True)
+        shapes = [{"shape": f"{names[k_[3]]} M={k_[4]} N={k_[5]} K={k_[6]} batch={k_[7]}", "launches_per_step": n_,
+                   "avg_ms": round(av_, 4), "tflops": round(fl_ / (av_ * 1e-3) / 1e12, 1)} for _, k_, fl_, av_, n_ in sym["shapes"][:4]]
         traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected), if this is that kernel
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-                for ent in json.load(f)["kernels"]:
-                    k_ = ent["key"]
-                    if (args.dtype, names[key[3]], key[4], key[5], key[6]) == (k_["dtype"], k_["gather"], k_["M"], k_["N"], k_["K"]) \
-                            and B == 128 and args.width == 1024:
-                        traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r01_pmc_traffic.json"
+        try:   # HBM bytes per launch (mean over the symbol's launches) from the committed PMC passes of this round's build
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            ent = pm["symbols"].get(symname)
+            if ent is not None and B == 128 and args.width == 1024 and args.dtype == "bf16" and not args.forward_only:
+                traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r02_pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"gemm_kernel<{args.dtype},{names[key[3]]},a{key[1]}b{key[2]}> M={key[4]} N={key[5]} K={key[6]} batch={key[7]}",
-                "launches_per_step": per_step, "avg_ms": round(avg_ms, 4),
-                "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
+                "kernel": symname, "launches_per_step": per_step, "avg_ms": round(avg_ms, 4),
+                "algorithmic_gflop_per_launch": round(flops / 1e9, 1), "ms_per_step": round(sym["ms"] / 2, 3),
+                "top_shapes": shapes,
                 "mfma_ms_per_step": round(sum(r[0] for r in rows) / 2, 2),
                 "all_mfma_tflops": round(sum(r[2] * len(prof[r[1]]["events"]) for r in rows) / sum(r[0] for r in rows) / 1e9, 1)}
 
     if rank == 0:
         out = {"metric": "line-images/sec (64x1024, B=128) fwd+bwd+CTC", "value": round(value, 1), "unit": "line-images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": ("HTR-VT base eval forward + CTC loss" if args.forward_only else
                                         "HTR-VT base (d768/4L/6h, nb_cls 80) reference iteration: SAM(AdamW) 2x(fwd + CTC + bwd) + EMA"
                                         if args.sam else

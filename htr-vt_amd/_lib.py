@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
 PROTOTYPES = {
     "htrvt_version": (i32, []),
     "htrvt_last_error": (C.c_char_p, []),
+    "htrvt_last_kernel": (C.c_char_p, []),
     "htrvt_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
     "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),

@@ -86,6 +86,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* fmt, ...);   // symbol (as rocprofv3 prints it) of the MFMA kernel an entry point launched
 int check_launch(const char* what);
 
 }  // namespace htrvt

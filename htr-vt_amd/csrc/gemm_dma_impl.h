@@ -829,6 +829,7 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, 1, zdim);
   if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * p.tiles_m * p.tiles_n, 1, 1);   // XCD-grouped K ranges
   hipLaunchKernelGGL(kern, grid, dim3(NTH), smem, st, p);
+  set_last_kernel("gemm_dma_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, AL, BL, GATHER, SPEC, NSTAGE);
   const int rc = check_launch("gemm_dma_kernel");
   return rc ? rc : 1;
 }

@@ -15,6 +15,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+
+void set_last_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -28,3 +37,4 @@ int check_launch(const char* what) {
 
 extern "C" int htrvt_version(void) { return 100; }
 extern "C" const char* htrvt_last_error(void) { return htrvt::g_err; }
+extern "C" const char* htrvt_last_kernel(void) { return htrvt::g_kernel; }

@@ -119,7 +119,8 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     else:   # algorithmic FLOPs of the convolution, whichever of fwd/dgrad/wgrad this launch is
         flops = 2.0 * geom.B * geom.Ho * geom.Wo * geom.Co * geom.taps * geom.Ci
     key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1))
-    PROFILE.setdefault(key, {"flops": flops, "events": []})["events"].append((e0, e1))
+    ent = PROFILE.setdefault(key, {"flops": flops, "events": [], "kernel": lib.htrvt_last_kernel().decode()})
+    ent["events"].append((e0, e1))
     return d
 
 

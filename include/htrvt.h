@@ -40,6 +40,9 @@ extern "C" {
 
 int htrvt_version(void);
 const char* htrvt_last_error(void);
+/* symbol of the MFMA kernel the last htrvt_gemm call of this thread launched, spelled as rocprofv3 prints it
+ * (e.g. "gemm_dma_kernel<256, 192, 0, 0, 2, 1, 2>"): lets bench.py name its roofline kernel by the profiler's symbol */
+const char* htrvt_last_kernel(void);
 
 /* One MFMA GEMM   C[m][n] = alpha * sum_k A(m,k) * B(n,k)  (+ epilogue).
  * Replaces: nn.Linear / torch.matmul (HTR_VT.py:22,29-37,170; timm Mlp fc1/fc2),

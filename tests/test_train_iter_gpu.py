@@ -39,6 +39,14 @@ def _masks(m, cfg, it):
     return out
 
 
+def _sam_scale(nsq, rho):
+    """scale = rho / (|g| + 1e-12) in float32 exactly as sam.py:20-21 evaluates it on float32 tensors -- torch's
+    `float / tensor` is reciprocal-then-multiply -- with correctly rounded (IEEE) operations: numpy on the host (a GPU
+    build of torch may use approximate device division / sqrt, which is not what is under test here)"""
+    n = np.sqrt(np.float32(nsq.item())) + np.float32(1e-12)
+    return float(np.float32(1.0) / n * np.float32(rho))
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # the flat kernels, one by one, against torch on identical inputs
 # --------------------------------------------------------------------------------------------------------------------
@@ -59,7 +67,7 @@ def test_sumsq_first_step_restore_match_torch():
     assert abs(float(nsq) - want) <= 4 * EPS32 * want, (float(nsq), want)
     rho = 0.05
     check(lib.htrvt_sam_first_step(ptr(p), ptr(g), ptr(old), n, rho, ptr(nsq), stream()), "sam_first_step")
-    scale = rho / (nsq.sqrt() + 1e-12)            # float32 tensor arithmetic, as sam.py:20-21
+    scale = _sam_scale(nsq, rho)
     assert torch.equal(old, p0)
     assert torch.equal(p, p0 + g * scale)         # e_w = g * scale (rounded), p.add_(e_w) (sam.py:24-25)
     check(lib.htrvt_sam_restore(ptr(p), ptr(old), n, stream()), "sam_restore")
@@ -129,7 +137,7 @@ def test_sam_iteration_stages_against_oracle_at_own_weights():
     nsq = tr._sam_buf[2]
     want_nsq = float(sum((g.double() ** 2).sum() for g in g1.values()))
     assert abs(float(nsq) - want_nsq) <= 8 * EPS32 * want_nsq
-    scale = rho / (nsq.sqrt() + 1e-12)
+    scale = _sam_scale(nsq, rho)
     for n, p in m.named_parameters():
         if n in g1:
             assert torch.equal(p.detach(), w0[n] + g1[n] * scale), n

@@ -352,7 +352,7 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, zdim);
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, st, p);
-  set_last_kernel("gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 4 ? "float" : "htrvt::bf16_t", BM, BN, AL, BL, GATHER);
+  set_last_kernel("gemm_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 4 ? "float" : "bf16_t", BM, BN, AL, BL, GATHER);
   return check_launch("gemm_kernel");
 }
 

@@ -20,6 +20,8 @@
 //     is conflict-free for both kinds of read (tools/lds_bank_check.py applies the banking rules to it).
 //   * K/V tiles (64 keys) are double buffered: global loads for tile t+1 are issued before the MFMAs of tile t and
 //     written to LDS after them (one barrier per tile).
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 using namespace htrvt;
@@ -113,6 +115,10 @@ __device__ __forceinline__ void stage_commit(const uint4 (&reg)[NL], char* tile)
   }
 }
 
+// v_exp_f32 directly: every argument here is <= ~0 (a score minus its row maximum / log-sum-exp), results below 2^-126
+// flush to zero, which is what a probability that small is worth; exp2f() would wrap the instruction in range scaling
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }   // the other 32-lane half's value
 
 // O[row][d] of a lane-per-row accumulator set: lane (r, hf) owns memory row `rowptr`, accumulator tile d register i is
@@ -133,7 +139,9 @@ __device__ __forceinline__ void store_lane_rows(const f32x16_t (&acc)[ND], bf16_
 // -------------------------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------------------------
-template <int HD>
+// DBG (timing ablations for tools/bench_attn.py, results are wrong when != 0): 1 no global loads inside the key loop,
+// 2 no softmax arithmetic, 4 no P V product
+template <int HD, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NTH = 256, QB = 128;
   constexpr int TILE_B = KT * HD * 2;
@@ -184,8 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // the last iteration re-stages its own tile into the idle buffer (nothing reads it): no conditional around the
     // loads, so the staging registers stay registers
     const int tn = min(t + 1, nt - 1);
-    stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
-    stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+    if constexpr (!(DBG & 1)) {
+      stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
+      stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+    }
     // S^T tiles: keys 32 c .. 32 c + 31 of this tile x the wave's 32 queries
     f32x16_t st[2];
 #pragma unroll
@@ -197,32 +207,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st[c], 0, 0, 0);
     }
     // online softmax for query r: this lane holds 32 of the tile's 64 keys, lane ^ 32 the other 32
-    float mx = -INFINITY;
+    if constexpr (!(DBG & 2)) {
+    float mx = -INFINITY;     // maximum of the raw scores (sl2 > 0: scaling commutes with the maximum)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        st[c][i] *= p.sl2;
-        mx = fmaxf(mx, st[c][i]);
-      }
-    mx = fmaxf(mx, xhalf(mx));
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[c][i]);
+    mx = fmaxf(mx, xhalf(mx)) * p.sl2;
     const float mn = fmaxf(m, mx);
-    const float alpha = exp2f(m - mn);
-    m = mn;
     float rs = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        st[c][i] = exp2f(st[c][i] - mn);
+        st[c][i] = fast_exp2(fmaf(st[c][i], p.sl2, -mn));
         rs += st[c][i];
       }
-    l = l * alpha + rs;
+    if (__any(mn > m)) {      // wave-uniform: the running maximum of some query moved -> rescale what is accumulated
+      const float alpha = fast_exp2(m - mn);
+      m = mn;
+      l *= alpha;
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+      for (int d = 0; d < ND; ++d)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    l += rs;
+    }
     // O^T += V^T P^T
+    if constexpr (!(DBG & 4))
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pr = exp2f(fmaf(st[i], p.sl2, -lse));
+        const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
         st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
       }
 #pragma unroll
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
         const float4 de = *reinterpret_cast<const float4*>(cst + KT + 32 * c + 8 * g + 4 * hf);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = exp2f(fmaf(st[4 * g + j], p.sl2, -(&ls.x)[j]));
+          const float pr = fast_exp2(fmaf(st[4 * g + j], p.sl2, -(&ls.x)[j]));
           st[4 * g + j] = pr;                                               // P
           dp[4 * g + j] = pr * (dp[4 * g + j] - (&de.x)[j]) * p.scale;      // dS
         }
@@ -465,11 +478,11 @@ int set_lds(K kern, int smem, const char* what) {
   return 0;
 }
 
-template <int HD>
+template <int HD, int DBG = 0>
 int launch_fwd(const AttnParams& p, hipStream_t st) {
   constexpr int smem = 2 * 2 * KT * HD * 2;
   static bool attr_done = false;
-  auto kern = attn_fwd_kernel<HD>;
+  auto kern = attn_fwd_kernel<HD, DBG>;
   if (!attr_done) {
     if (int rc = set_lds(kern, smem, "attn_fwd")) return rc;
     attr_done = true;
@@ -516,7 +529,15 @@ extern "C" int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, in
   p.scale = scale;
   p.sl2 = scale * LOG2E;
   hipStream_t st = (hipStream_t)stream;
-  if (hd == 128) return launch_fwd<128>(p, st);
+  if (hd == 128) {
+    static const int dbg = getenv("HTRVT_ATTN_DBG") ? atoi(getenv("HTRVT_ATTN_DBG")) : 0;   // timing ablations (bench_attn.py)
+    if (dbg == 1) return launch_fwd<128, 1>(p, st);
+    if (dbg == 2) return launch_fwd<128, 2>(p, st);
+    if (dbg == 3) return launch_fwd<128, 3>(p, st);
+    if (dbg == 6) return launch_fwd<128, 6>(p, st);
+    if (dbg == 7) return launch_fwd<128, 7>(p, st);
+    return launch_fwd<128>(p, st);
+  }
   if (hd == 64) return launch_fwd<64>(p, st);
   return launch_fwd<32>(p, st);
 }

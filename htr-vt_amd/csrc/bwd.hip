@@ -573,12 +573,24 @@ __global__ __launch_bounds__(NT) void conv1_wgrad_kernel(const void* __restrict_
 }
 
 // out[c] += sum_r partial[r][c]   (float32 rows)
-__global__ __launch_bounds__(NT) void rowsum_f32_kernel(const float* __restrict__ partial, int rows, int cols,
-                                                        float* __restrict__ out) {
-  const int c = blockIdx.x * NT + threadIdx.x;
+// one thread per column, rows added in ascending order (reproducible); 8 independent loads in flight per thread, 64-thread
+// blocks so that a few hundred columns still spread over several CUs (this runs ~40 times per step, latency-bound)
+constexpr int RS_NT = 64;
+__global__ __launch_bounds__(RS_NT) void rowsum_f32_kernel(const float* __restrict__ partial, int rows, int cols,
+                                                           float* __restrict__ out) {
+  const int c = blockIdx.x * RS_NT + threadIdx.x;
   if (c >= cols) return;
+  const float* src = partial + c;
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += partial[(long long)r * cols + c];
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(r + u) * cols];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; r < rows; ++r) a += src[(long long)r * cols];
   out[c] += a;
 }
 
@@ -647,7 +659,9 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
                                                    float w2, float eps, float bc2s, float neg_step) {
   // the statement order of torch.optim.AdamW's single-tensor step (torch/optim/adamw.py): p *= 1 - lr*wd;
   // m.lerp_(g, 1 - beta1); v = v*beta2 + (1 - beta2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * m/denom.
-  // Scalars are formed in double on the host (Python floats are doubles) and rounded once.
+  // Scalars are formed in double on the host (Python floats are doubles) and rounded once.  One rounding per operation:
+  // no FMA contraction in this function; `/` and sqrtf are the correctly rounded forms (hipcc default).
+#pragma clang fp contract(off)
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -658,11 +672,11 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
       const float gj = (&gg.x)[j];
       float& mj = (&mm.x)[j];
       float& vj = (&vv.x)[j];
-      pj = __fmul_rn(pj, decay);
-      mj = __fadd_rn(mj, __fmul_rn(w1, __fsub_rn(gj, mj)));
-      vj = __fadd_rn(__fmul_rn(vj, b2), __fmul_rn(__fmul_rn(w2, gj), gj));
-      const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vj), bc2s), eps);
-      pj = __fadd_rn(pj, __fmul_rn(neg_step, __fdiv_rn(mj, denom)));
+      pj = pj * decay;
+      mj = mj + w1 * (gj - mj);
+      vj = vj * b2 + (w2 * gj) * gj;
+      const float denom = sqrtf(vj) / bc2s + eps;
+      pj = pj + neg_step * (mj / denom);
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
@@ -751,12 +765,12 @@ extern "C" int htrvt_colsum(const void* x, int64_t rows, int cols, int64_t ld, f
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(1024), 0, (hipStream_t)stream, (const T*)x, (long long)rows,
                                        cols, (long long)ld, out, keep, keep_mod > 0 ? keep_mod : 1, workspace));
   if (splits > 1)
-    hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, workspace, splits, cols, out);
+    hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + RS_NT - 1) / RS_NT), dim3(RS_NT), 0, (hipStream_t)stream, workspace, splits, cols, out);
   return check_launch("colsum");
 }
 
 extern "C" int htrvt_rowsum_f32(const float* partial, int rows, int cols, float* out, void* stream) {
-  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, partial, rows, cols, out);
+  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((cols + RS_NT - 1) / RS_NT), dim3(RS_NT), 0, (hipStream_t)stream, partial, rows, cols, out);
   return check_launch("rowsum_f32");
 }
 
@@ -840,7 +854,7 @@ extern "C" int htrvt_conv1_wgrad(const void* img, const float* stats, const void
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_wgrad_kernel<T>, dim3(nblk), dim3(NT), smem, st, img, stats, (const T*)dy,
                                        partial, B, H, W, C, nthr, img_u8));
-  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((C * 9 + NT - 1) / NT), dim3(NT), 0, st, partial, nblk, C * 9, dw);
+  hipLaunchKernelGGL(rowsum_f32_kernel, dim3((C * 9 + RS_NT - 1) / RS_NT), dim3(RS_NT), 0, st, partial, nblk, C * 9, dw);
   return check_launch("conv1_wgrad");
 }
 

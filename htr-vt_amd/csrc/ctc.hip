@@ -156,6 +156,16 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
     float xn = act ? x[(long long)(T - 1) * C + e] : 0.f;          // emission and alpha of the step about to run
     float an = act ? A[(long long)(T - 1) * Smax + tid] : 0.f;
     float gn = tid < C ? x[(long long)(T - 1) * C + tid] : 0.f;    // logit of class `tid` for the gradient row
+    // the first four states of class `tid` in registers (their occupancies are then four independent LDS reads per step
+    // instead of a dependent walk through the list); `rest` continues the list for a label that occurs more often
+    int cs0 = -1, cs1 = -1, cs2 = -1, cs3 = -1, rest = -1;
+    if (tid > 0 && tid < C) {
+      cs0 = head[tid];
+      cs1 = cs0 >= 0 ? nxt[cs0] : -1;
+      cs2 = cs1 >= 0 ? nxt[cs1] : -1;
+      cs3 = cs2 >= 0 ? nxt[cs2] : -1;
+      rest = cs3 >= 0 ? nxt[cs3] : -1;
+    }
     for (int t = T - 1; t >= 0; --t) {
       const float* xt = x + (long long)t * C;
       const float l = lse[t];
@@ -198,6 +208,11 @@ __global__ __launch_bounds__(NT) void ctc_kernel(const float* __restrict__ logit
         if (c == 0) {
 #pragma unroll
           for (int w = 0; w < NT / 64; ++w) oc += ow[w];
+        } else if (c == tid) {     // ascending state order, as the list: the sum is the same on every run
+          const float o0 = cs0 >= 0 ? os[cs0] : 0.f, o1 = cs1 >= 0 ? os[cs1] : 0.f;
+          const float o2 = cs2 >= 0 ? os[cs2] : 0.f, o3 = cs3 >= 0 ? os[cs3] : 0.f;
+          oc = ((o0 + o1) + o2) + o3;
+          for (int s2 = rest; s2 >= 0; s2 = nxt[s2]) oc += os[s2];
         } else {
           for (int s2 = head[c]; s2 >= 0; s2 = nxt[s2]) oc += os[s2];
         }

@@ -9,6 +9,12 @@
 // All HBM-bound streaming kernels.
 #include "common.h"
 
+// Every kernel here promises torch's elementwise rounding (one rounding per product / sum): no FMA contraction in this
+// file.  (The __f*_rn device functions do NOT promise it on this toolchain: without OCML_BASIC_ROUNDED_OPERATIONS
+// __fadd_rn(x, y) is plain `x + y`, open to contraction, and __fsqrt_rn is the approximate native square root; plain
+// `/` and sqrtf() are the correctly rounded forms under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.)
+#pragma clang fp contract(off)
+
 using namespace htrvt;
 
 namespace {
@@ -51,16 +57,16 @@ __global__ __launch_bounds__(NT) void sumsq_final_kernel(const float* __restrict
 __global__ __launch_bounds__(NT) void sam_first_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ old_p,
                                                        long long n4, float rho, const float* __restrict__ norm_sq) {
   // scale = rho / (|g| + 1e-12) as torch evaluates `float / tensor` (Tensor.__rtruediv__): reciprocal, then multiply
-  const float scale = __fmul_rn(__frcp_rn(__fadd_rn(__fsqrt_rn(norm_sq[0]), 1e-12f)), rho);
+  const float scale = (1.0f / (sqrtf(norm_sq[0]) + 1e-12f)) * rho;
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
     reinterpret_cast<float4*>(old_p)[i] = pp;
-    // e_w = 1.0 * grad * scale, rounded, then added (sam.py:24-25): explicit round-to-nearest ops, never contracted to an FMA
-    pp.x = __fadd_rn(pp.x, __fmul_rn(gg.x, scale));
-    pp.y = __fadd_rn(pp.y, __fmul_rn(gg.y, scale));
-    pp.z = __fadd_rn(pp.z, __fmul_rn(gg.z, scale));
-    pp.w = __fadd_rn(pp.w, __fmul_rn(gg.w, scale));
+    // e_w = 1.0 * grad * scale, rounded, then added (sam.py:24-25); FMA contraction is off in this file
+    pp.x = pp.x + gg.x * scale;
+    pp.y = pp.y + gg.y * scale;
+    pp.z = pp.z + gg.z * scale;
+    pp.w = pp.w + gg.w * scale;
     reinterpret_cast<float4*>(p)[i] = pp;
   }
 }
@@ -77,16 +83,16 @@ __global__ __launch_bounds__(NT) void ema_update_kernel(const HtrvtEmaEntry* __r
     long long* ema = reinterpret_cast<long long*>(e.ema);
     const long long* mod = reinterpret_cast<const long long*>(e.model);
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < e.numel; i += (long long)gridDim.x * NT) {
-      const float a = __fmul_rn((float)ema[i], d), b = __fmul_rn(omd, (float)mod[i]);
-      ema[i] = (long long)__fadd_rn(a, b);     // float math, truncating copy_ (utils.py:173 on an int64 entry)
+      const float a = (float)ema[i] * d, b = omd * (float)mod[i];
+      ema[i] = (long long)(a + b);     // float math, truncating copy_ (utils.py:173 on an int64 entry)
     }
     return;
   }
   float* ema = reinterpret_cast<float*>(e.ema);
   const float* mod = reinterpret_cast<const float*>(e.model);
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < e.numel; i += (long long)gridDim.x * NT) {
-    const float a = __fmul_rn(ema[i], d), b = __fmul_rn(omd, mod[i]);   // ema*d + (1-d)*model, each product rounded
-    ema[i] = __fadd_rn(a, b);
+    const float a = ema[i] * d, b = omd * mod[i];   // ema*d + (1-d)*model, each product rounded (contraction is off)
+    ema[i] = a + b;
   }
 }
 

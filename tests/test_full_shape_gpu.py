@@ -1,0 +1,106 @@
+"""Parity at the HEADLINE shape: HTR-VT base (d768 / 4L / 6h, nb_cls 80), 64x1024 lines, batch 128 -- BASELINE.json
+configs 2 / 3, the shape bench.py measures.  Kernel variants are picked per shape (gemm_dma.hip pick_bn /
+use_loader_waves, engine._split_k incl. the XCD-grouped multiples of 8, parity-class dgrad launches), so this is the
+only place the bench's hot variants meet the oracle end to end.
+
+  * float32 eval logits vs the oracle: eval-mode BatchNorm makes samples independent, so an 8-image subset of the
+    batch through the CPU oracle pins the whole batch's kernels (every launch still runs at B = 128): <= 1e-3;
+  * float32 train-mode (batch statistics over all 128 images, span mask on) logits and CTC loss vs the oracle run on
+    the full batch (forward only, ~20-40 s of host time): <= 1e-3 on the logits, 1e-5 relative on the loss;
+  * bfloat16 (the measured path): reported against the same oracle outputs and gated loosely."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import htrvt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+B, W, NB_CLS = 128, 1024, 80
+
+
+@pytest.fixture(scope="module")
+def setup():
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    cfg = O.Config(NB_CLS, (64, W), embed_dim=768, depth=4, num_heads=6)
+    sd = O.init_state_dict(cfg, seed=123, randomize_affine=True)
+    x, targets, lengths = O.synthetic_batch(B, 64, W, NB_CLS, cfg.num_patches, seed=0)
+    torch.manual_seed(7)
+    keep = O.span_mask(cfg.num_patches, 0.4, 8)
+    with torch.no_grad():
+        sub = torch.arange(0, B, 16)                                   # 8 images spread over the batch
+        ref_eval = O.forward(sd, cfg, x[sub], train=False)
+        ref_train = O.forward(sd, cfg, x, keep_mask=keep, train=True)
+    lp = ref_train.double().permute(1, 0, 2).log_softmax(2)             # compute_loss (train.py:21-30) in float64
+    ref_nll = torch.nn.functional.ctc_loss(lp, torch.from_numpy(targets), torch.full((B,), lp.shape[0], dtype=torch.int32),
+                                           torch.from_numpy(lengths), blank=0, reduction="none", zero_infinity=True).numpy()
+    return dict(cfg=cfg, sd=sd, x=x, targets=targets, lengths=lengths, keep=keep, sub=sub, ref_eval=ref_eval,
+                ref_train=ref_train, ref_nll=np.asarray(ref_nll))
+
+
+def _model(cfg, sd, dtype):
+    from htrvt_amd.model import HTR_VT
+    m = HTR_VT.MaskedAutoencoderViT(cfg.nb_cls, img_size=[cfg.H, cfg.W], patch_size=cfg.patch, embed_dim=cfg.D,
+                                    depth=cfg.depth, num_heads=cfg.heads, mlp_ratio=4,
+                                    norm_layer=partial(nn.LayerNorm, eps=1e-6), compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_headline_shape_eval_and_train_forward(setup, dtype):
+    from htrvt_amd.ctc import ctc_forward_backward
+    s = setup
+    m = _model(s["cfg"], s["sd"], dtype)
+    xd = s["x"].cuda()
+    m.eval()
+    with torch.no_grad():
+        y = m(xd)
+    err_eval = (y[s["sub"].cuda()].cpu() - s["ref_eval"]).abs().max().item()
+    m.train()
+    with torch.no_grad():
+        yt = m(xd, keep_mask=s["keep"])
+        nll, _ = ctc_forward_backward(yt, s["targets"], s["lengths"], want_grad=False)
+    err_train = (yt.cpu() - s["ref_train"]).abs().max().item()
+    rel_loss = abs(float(nll.mean()) - float(s["ref_nll"].mean())) / abs(float(s["ref_nll"].mean()))
+    agree = (yt.cpu().argmax(-1) == s["ref_train"].argmax(-1)).float().mean().item()
+    print(f"{dtype} B=128 64x1024 d768: eval logits max-abs {err_eval:.3e}, train logits max-abs {err_train:.3e}, "
+          f"CTC loss rel {rel_loss:.3e}, arg-max agreement {agree:.4f}")
+    if dtype == torch.float32:
+        assert err_eval < 1e-3 and err_train < 1e-3
+        assert rel_loss < 1e-5
+    else:
+        assert err_eval < 0.25 and err_train < 0.25 and agree > 0.95 and rel_loss < 2e-2
+
+
+def test_headline_shape_training_step_bf16_vs_f32_gradients(setup):
+    """one fwd + CTC + bwd at the bench shape on both paths: the bf16 step's gradients against the float32 parity path's
+    (which the smaller-shape tests pin to the oracle), every tensor by cosine; exercises split-K 8 / 72 wgrad, the fused
+    dgrad epilogues, the fused attention backward and the parity-class launches at exactly the bench's shapes"""
+    import htrvt_amd
+    s = setup
+    grads = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = _model(s["cfg"], s["sd"], dtype).train()
+        y = m(s["x"].cuda(), keep_mask=s["keep"])
+        loss = htrvt_amd.ctc_loss(y, s["targets"], s["lengths"])
+        loss.backward()
+        grads[dtype] = ({n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}, float(loss))
+        del m, y, loss
+        torch.cuda.empty_cache()
+    g32, l32 = grads[torch.float32]
+    g16, l16 = grads[torch.bfloat16]
+    assert abs(l32 - float(s["ref_nll"].mean())) < 1e-5 * abs(l32)
+    assert abs(l16 - l32) < 2e-2 * abs(l32)
+    worst = (1.0, None)
+    for n in g32:
+        if g32[n].numel() < 64 or n.endswith("attn.qkv.bias"):
+            continue
+        a, b_ = g16[n].flatten().double(), g32[n].flatten().double()
+        cos = float(a @ b_ / (a.norm() * b_.norm() + 1e-30))
+        worst = min(worst, (cos, n))
+        assert cos > 0.9, (n, cos)
+    print("B=128 64x1024 bf16 vs f32 training-step gradients: worst cosine", worst)

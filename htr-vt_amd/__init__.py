@@ -3,6 +3,7 @@ forward / training hot path.  The directory is named `htr-vt_amd`; import it as
 `htrvt_amd` (see /htrvt_amd.py at the repo root)."""
 from . import _lib  # noqa: F401  (raises loudly when libhtrvt_hip.so is missing)
 from .ctc import ctc_forward_backward, ctc_loss, greedy_decode  # noqa: F401
+from .data import prepare_lines  # noqa: F401
 from .ema import ModelEma  # noqa: F401
 from .engine import Engine, ModelShape  # noqa: F401
 

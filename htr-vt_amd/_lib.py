@@ -86,6 +86,8 @@ PROTOTYPES = {
     "htrvt_ema_update": (i32, [vp, i32, i64, f64, vp]),
     "htrvt_ctc_greedy_decode": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp]),
     "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
+    "htrvt_line_max_scale": (i32, []),
+    "htrvt_line_prepare": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),
     "htrvt_ctc_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
 }

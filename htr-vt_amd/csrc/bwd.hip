@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
       mj = mj + w1 * (gj - mj);
       vj = vj * b2 + (w2 * gj) * gj;
       const float denom = sqrtf(vj) / bc2s + eps;
-      pj = pj + neg_step * (mj / denom);
+      pj = pj + (neg_step * mj) / denom;     // addcdiv_: self + value * t1 / t2, evaluated left to right as ATen does
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;

@@ -250,6 +250,22 @@ int htrvt_ema_update(const HtrvtEmaEntry* table, int count, int64_t max_numel, d
 int htrvt_ctc_greedy_decode(const float* logits, int B, int T, int C, int64_t ld, int ncharacter, int32_t* out,
                             int32_t* out_len, void* stream);
 
+/* ---- in front of the path: the loader's per-image preparation -------------------------------------
+ * data/dataset.py:104-135 for a ragged batch of grey uint8 scans: aspect-preserving resize to height H (npThum: width' =
+ * min(int(w * H / h), W), PIL.Image.resize = Pillow's 8-bit BICUBIC resampler, restated bit for bit), img_as_float32 and
+ * right pad with 1.0 -- delivered as the uint8 batch dst [B][H][W] (255 = 1.0) that the model reads as value / 255.
+ * src: all scans back to back; table[i] (device) = {byte offset of scan i in src, byte offset of its scratch rows in tmp
+ * (h_i * W bytes each), h_i, w_i}; max_src_h = max h_i.  Every scale factor h_i / H and w_i / width' must be
+ * <= htrvt_line_max_scale() (the tap table of one output pixel is bounded). */
+typedef struct HtrvtLineImage {
+  int64_t src_offset;
+  int64_t tmp_offset;
+  int32_t h, w;
+} HtrvtLineImage;
+int htrvt_line_max_scale(void);
+int htrvt_line_prepare(const uint8_t* src, const HtrvtLineImage* table, uint8_t* tmp, uint8_t* dst, int B, int H, int W,
+                       int max_src_h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

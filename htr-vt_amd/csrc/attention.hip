@@ -139,8 +139,9 @@ __device__ __forceinline__ void store_lane_rows(const f32x16_t (&acc)[ND], bf16_
 // -------------------------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------------------------
-// DBG (timing ablations for tools/bench_attn.py, results are wrong when != 0): 1 no global loads inside the key loop,
-// 2 no softmax arithmetic, 4 no P V product
+// DBG: compile-time timing ablations (results are wrong when != 0; instantiate by hand for an experiment): 1 no global
+// loads inside the key loop, 2 no softmax arithmetic, 4 no P V product.  Measured at B=128, N=256, hd=128:
+// 58.8 us as shipped, 50.6 without the softmax, 36.4 without softmax and P V; the HBM floor of the launch is 32 us.
 template <int HD, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NTH = 256, QB = 128;
@@ -529,15 +530,7 @@ extern "C" int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, in
   p.scale = scale;
   p.sl2 = scale * LOG2E;
   hipStream_t st = (hipStream_t)stream;
-  if (hd == 128) {
-    static const int dbg = getenv("HTRVT_ATTN_DBG") ? atoi(getenv("HTRVT_ATTN_DBG")) : 0;   // timing ablations (bench_attn.py)
-    if (dbg == 1) return launch_fwd<128, 1>(p, st);
-    if (dbg == 2) return launch_fwd<128, 2>(p, st);
-    if (dbg == 3) return launch_fwd<128, 3>(p, st);
-    if (dbg == 6) return launch_fwd<128, 6>(p, st);
-    if (dbg == 7) return launch_fwd<128, 7>(p, st);
-    return launch_fwd<128>(p, st);
-  }
+  if (hd == 128) return launch_fwd<128>(p, st);
   if (hd == 64) return launch_fwd<64>(p, st);
   return launch_fwd<32>(p, st);
 }

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Time the fused attention kernels (csrc/attention.hip) at the model shapes, A/B in one process.
-    python tools/bench_attn.py [--dbg]      # --dbg: forward timing ablations (HTRVT_ATTN_DBG), one subprocess each"""
+    python tools/bench_attn.py"""
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +14,6 @@ def run():
     from htrvt_amd._lib import check, lib
     from htrvt_amd.ops import ptr, stream
     shapes = [(128, 256, 6, 128), (64, 512, 6, 128), (128, 128, 6, 128), (256, 256, 8, 64)]
-    if os.environ.get("HTRVT_ATTN_DBG"):
-        shapes = shapes[:1]
     for B, N, h, hd in shapes:
         D = h * hd
         qkv = (torch.randn(B * N, 3 * D, device="cuda") * 1.2).bfloat16()
@@ -46,12 +43,8 @@ def run():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 20 * 1e3
             res.append(f"{us:8.1f} us {flops / us / 1e6:7.1f} TF/s {byts / us / 1e6:5.2f} TB/s(min bytes)")
-        print(f"B={B} N={N} h={h} hd={hd} dbg={os.environ.get('HTRVT_ATTN_DBG', '0')}: fwd {res[0]} | bwd(dq+dkv, 7 products) {res[1]}", flush=True)
+        print(f"B={B} N={N} h={h} hd={hd}: fwd {res[0]} | bwd(dq+dkv, 7 products) {res[1]}", flush=True)
 
 
 if __name__ == "__main__":
-    if "--dbg" in sys.argv:
-        for d in ("0", "1", "2", "3", "6", "7"):
-            subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, HTRVT_ATTN_DBG=d), check=False)
-    else:
-        run()
+    run()

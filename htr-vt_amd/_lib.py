@@ -53,10 +53,10 @@ PROTOTYPES = {
     "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
-    "htrvt_softmax_rows": (i32, [vp, vp, i64, i32, i32, vp]),
+    "htrvt_softmax_rows": (i32, [vp, vp, i64, i32, i32, vp, i64, vp]),
     "htrvt_attn_supported": (i32, [i32, i32, i32]),
-    "htrvt_attn_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
-    "htrvt_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "htrvt_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "htrvt_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "htrvt_seq_whiten_fwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
     "htrvt_seq_whiten_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_layernorm_bwd_blocks": (i32, [i64]),

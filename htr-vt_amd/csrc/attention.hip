@@ -38,6 +38,8 @@ struct AttnParams {
   const bf16_t* dout;  // backward: gradient of out
   const bf16_t* o;     // backward: forward output
   bf16_t* dqkv;        // backward: gradient of qkv
+  const float* bias;   // [h][N][N] additive score bias (natural-log units, added after the scale) or NULL
+  float* dbias;        // backward: [h][N][N] += sum_b dS (float atomics) or NULL
   int B, N, h;
   float sl2;           // scale * log2(e)
   float scale;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void store_lane_rows(const f32x16_t (&acc)[ND], bf16_
 // DBG: compile-time timing ablations (results are wrong when != 0; instantiate by hand for an experiment): 1 no global
 // loads inside the key loop, 2 no softmax arithmetic, 4 no P V product.  Measured at B=128, N=256, hd=128:
 // 58.8 us as shipped, 50.6 without the softmax, 36.4 without softmax and P V; the HBM floor of the launch is 32 us.
-template <int HD, int DBG = 0>
+template <int HD, int DBG = 0, bool BIAS = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NTH = 256, QB = 128;
   constexpr int TILE_B = KT * HD * 2;
@@ -209,19 +211,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     // online softmax for query r: this lane holds 32 of the tile's 64 keys, lane ^ 32 the other 32
     if constexpr (!(DBG & 2)) {
-    float mx = -INFINITY;     // maximum of the raw scores (sl2 > 0: scaling commutes with the maximum)
+    float mx = -INFINITY;
+    if constexpr (BIAS) {
+      // score = S * scale + bias[h][q][k] (relative-position bias, window / padding mask as a large negative number):
+      // this lane's query row, four consecutive keys per accumulator register quad
+      const float* brow = p.bias + ((long long)hh * p.N + q0 + r) * p.N + t * KT + 4 * hf;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[c][i]);
-    mx = fmaxf(mx, xhalf(mx)) * p.sl2;
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(brow + 32 * c + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            st[c][4 * g + j] = fmaf(st[c][4 * g + j], p.sl2, (&bv.x)[j] * LOG2E);
+            mx = fmaxf(mx, st[c][4 * g + j]);
+          }
+        }
+      mx = fmaxf(mx, xhalf(mx));
+    } else {                  // maximum of the raw scores (sl2 > 0: scaling commutes with the maximum)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[c][i]);
+      mx = fmaxf(mx, xhalf(mx)) * p.sl2;
+    }
     const float mn = fmaxf(m, mx);
     float rs = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        st[c][i] = fast_exp2(fmaf(st[c][i], p.sl2, -mn));
+        st[c][i] = BIAS ? fast_exp2(st[c][i] - mn) : fast_exp2(fmaf(st[c][i], p.sl2, -mn));
         rs += st[c][i];
       }
     if (__any(mn > m)) {      // wave-uniform: the running maximum of some query moved -> rescale what is accumulated
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 // lane owns one query, K / V tiles stream through LDS, P is recomputed from the saved lse2.
 //   S^T = K Q^T ; P^T = exp2(S^T sl2 - lse2[q]) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta[q]) scale ; dQ^T += K^T dS^T
 // -------------------------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool BIAS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p, float* __restrict__ delta) {
   constexpr int NTH = 256, QB = 128;
   constexpr int TILE_B = KT * HD * 2;
@@ -335,10 +355,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vt, 32 * c, s, lane), dof[s], dp, 0, 0, 0);
       }
+      if constexpr (BIAS) {
+        const float* brow = p.bias + ((long long)hh * p.N + q0 + r) * p.N + t * KT + 32 * c + 4 * hf;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
-        st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(brow + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float pr = fast_exp2(fmaf(st[4 * g + j], p.sl2, fmaf((&bv.x)[j], LOG2E, -lse)));
+            st[4 * g + j] = pr * (dp[4 * g + j] - dl) * p.scale;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
+          st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -362,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
 //   S = Q K^T ; P = exp2(S sl2 - lse2[q]) ; dP = dO V^T ; dS = P (dP - delta[q]) scale ; dV^T += dO^T P ; dK^T += Q^T dS
 // One wave per SIMD (the two 32 x HD accumulator sets + the K / V fragments need > 256 registers).
 // -------------------------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool BIAS = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p, const float* __restrict__ delta) {
   constexpr int NTH = 256, KB = 128;
   constexpr int TILE_B = KT * HD * 2;
@@ -444,9 +477,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
         const float4 de = *reinterpret_cast<const float4*>(cst + KT + 32 * c + 8 * g + 4 * hf);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = fast_exp2(fmaf(st[4 * g + j], p.sl2, -(&ls.x)[j]));
+          float sb = -(&ls.x)[j];
+          long long boff = 0;
+          if constexpr (BIAS) {     // bias[h][query][key]: lanes of a half are 32 consecutive keys of one query row
+            boff = ((long long)hh * p.N + t * KT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
+            sb = fmaf(p.bias[boff], LOG2E, sb);
+          }
+          const float pr = fast_exp2(fmaf(st[4 * g + j], p.sl2, sb));
+          const float dsu = pr * (dp[4 * g + j] - (&de.x)[j]);              // d(score): gradient of the bias entry too
+          if constexpr (BIAS) {
+            if (p.dbias != nullptr) atomicAdd(p.dbias + boff, dsu);         // summed over the batch
+          }
           st[4 * g + j] = pr;                                               // P
-          dp[4 * g + j] = pr * (dp[4 * g + j] - (&de.x)[j]) * p.scale;      // dS
+          dp[4 * g + j] = dsu * p.scale;                                    // dS
         }
       }
 #pragma unroll
@@ -479,11 +522,11 @@ int set_lds(K kern, int smem, const char* what) {
   return 0;
 }
 
-template <int HD, int DBG = 0>
+template <int HD, bool BIAS>
 int launch_fwd(const AttnParams& p, hipStream_t st) {
   constexpr int smem = 2 * 2 * KT * HD * 2;
   static bool attr_done = false;
-  auto kern = attn_fwd_kernel<HD, DBG>;
+  auto kern = attn_fwd_kernel<HD, 0, BIAS>;
   if (!attr_done) {
     if (int rc = set_lds(kern, smem, "attn_fwd")) return rc;
     attr_done = true;
@@ -492,13 +535,13 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
   return check_launch("attn_fwd");
 }
 
-template <int HD>
+template <int HD, bool BIAS>
 int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
   constexpr int smem_dq = 2 * 2 * KT * HD * 2;
   constexpr int smem_kv = 2 * (2 * KT * HD * 2 + 2 * KT * 4);
   static bool attr_done = false;
-  auto kq = attn_bwd_dq_kernel<HD>;
-  auto kkv = attn_bwd_dkv_kernel<HD>;
+  auto kq = attn_bwd_dq_kernel<HD, BIAS>;
+  auto kkv = attn_bwd_dkv_kernel<HD, BIAS>;
   if (!attr_done) {
     if (int rc = set_lds(kq, smem_dq, "attn_bwd_dq")) return rc;
     if (int rc = set_lds(kkv, smem_kv, "attn_bwd_dkv")) return rc;
@@ -516,8 +559,8 @@ extern "C" int htrvt_attn_supported(int N, int hd, int dtype) {
   return dtype == HTRVT_BF16 && N >= 128 && N % 128 == 0 && (hd == 32 || hd == 64 || hd == 128);
 }
 
-extern "C" int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, int N, int heads, int hd, float scale, int dtype,
-                              void* stream) {
+extern "C" int htrvt_attn_fwd(const void* qkv, const float* bias, void* out, float* lse2, int B, int N, int heads, int hd,
+                              float scale, int dtype, void* stream) {
   HTRVT_REQUIRE(qkv && out, "htrvt_attn_fwd: null operand");
   HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
                 "htrvt_attn_fwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
@@ -526,17 +569,24 @@ extern "C" int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, in
   p.qkv = (const bf16_t*)qkv;
   p.out = (bf16_t*)out;
   p.lse2 = lse2;
+  p.bias = bias;
   p.B = B; p.N = N; p.h = heads;
   p.scale = scale;
   p.sl2 = scale * LOG2E;
   hipStream_t st = (hipStream_t)stream;
-  if (hd == 128) return launch_fwd<128>(p, st);
-  if (hd == 64) return launch_fwd<64>(p, st);
-  return launch_fwd<32>(p, st);
+  if (bias != nullptr) {
+    if (hd == 128) return launch_fwd<128, true>(p, st);
+    if (hd == 64) return launch_fwd<64, true>(p, st);
+    return launch_fwd<32, true>(p, st);
+  }
+  if (hd == 128) return launch_fwd<128, false>(p, st);
+  if (hd == 64) return launch_fwd<64, false>(p, st);
+  return launch_fwd<32, false>(p, st);
 }
 
-extern "C" int htrvt_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, float* delta, void* dqkv,
-                              int B, int N, int heads, int hd, float scale, int dtype, void* stream) {
+extern "C" int htrvt_attn_bwd(const void* qkv, const float* bias, const void* out, const void* dout, const float* lse2,
+                              float* delta, void* dqkv, float* dbias, int B, int N, int heads, int hd, float scale, int dtype,
+                              void* stream) {
   HTRVT_REQUIRE(qkv && out && dout && lse2 && delta && dqkv, "htrvt_attn_bwd: null operand");
   HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
                 "htrvt_attn_bwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
@@ -546,11 +596,19 @@ extern "C" int htrvt_attn_bwd(const void* qkv, const void* out, const void* dout
   p.dout = (const bf16_t*)dout;
   p.lse2 = const_cast<float*>(lse2);
   p.dqkv = (bf16_t*)dqkv;
+  p.bias = bias;
+  p.dbias = dbias;
   p.B = B; p.N = N; p.h = heads;
   p.scale = scale;
   p.sl2 = scale * LOG2E;
+  HTRVT_REQUIRE(dbias == nullptr || bias != nullptr, "htrvt_attn_bwd: dbias without bias");
   hipStream_t st = (hipStream_t)stream;
-  if (hd == 128) return launch_bwd<128>(p, delta, st);
-  if (hd == 64) return launch_bwd<64>(p, delta, st);
-  return launch_bwd<32>(p, delta, st);
+  if (bias != nullptr) {
+    if (hd == 128) return launch_bwd<128, true>(p, delta, st);
+    if (hd == 64) return launch_bwd<64, true>(p, delta, st);
+    return launch_bwd<32, true>(p, delta, st);
+  }
+  if (hd == 128) return launch_bwd<128, false>(p, delta, st);
+  if (hd == 64) return launch_bwd<64, false>(p, delta, st);
+  return launch_bwd<32, false>(p, delta, st);
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const T* __restrict__
 // ------------------------------------------------------------------ row softmax: float32 scores -> P (T)
 template <typename T>
 __global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows,
-                                                          int n) {
+                                                          int n, const float* __restrict__ bias, long long bias_rows) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -79,6 +79,10 @@ __global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restric
     const int c = lane + 64 * k;
     if (c < nchunk) {
       v[k] = reinterpret_cast<const float4*>(s + row * n)[c];
+      if (bias != nullptr) {   // additive score bias, row r of the scores uses bias row r % bias_rows ([heads][N][n] per batch entry)
+        const float4 b = reinterpret_cast<const float4*>(bias + (row % bias_rows) * n)[c];
+        v[k].x += b.x; v[k].y += b.y; v[k].z += b.z; v[k].w += b.w;
+      }
       mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
     }
   }
@@ -151,15 +155,18 @@ extern "C" int htrvt_layernorm_fwd(const void* x, const float* gamma, const floa
   return check_launch("layernorm_fwd");
 }
 
-extern "C" int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, void* stream) {
+extern "C" int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, const float* bias, int64_t bias_rows,
+                                  void* stream) {
+  HTRVT_REQUIRE(bias == nullptr || bias_rows > 0, "htrvt_softmax_rows: bias needs bias_rows > 0");
   HTRVT_REQUIRE(n % 4 == 0 && n / 4 <= 64 * MAXC, "htrvt_softmax_rows: n=%d unsupported (multiple of 4, <= %d)", n,
                 64 * MAXC * 4);
   dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == HTRVT_BF16)
     hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, s, (bf16_t*)p, (long long)rows,
-                       n);
+                       n, bias, (long long)(bias ? bias_rows : 1));
   else
-    hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, s, (float*)p, (long long)rows, n);
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, s, (float*)p, (long long)rows, n,
+                       bias, (long long)(bias ? bias_rows : 1));
   return check_launch("softmax_rows");
 }
 

@@ -491,7 +491,7 @@ class Engine:
             if self.fused_attention and lib.htrvt_attn_supported(N, hd, self.dti):
                 # bf16: one launch, scores / probabilities stay on chip; lse2 is what the recomputing backward needs
                 Pm, lse = None, (self._empty(B * h, N, dtype=torch.float32) if save else None)
-                check(lib.htrvt_attn_fwd(ptr(qkv), ptr(O), ptr(lse), B, N, h, hd, scale, self.dti, st), "attn_fwd")
+                check(lib.htrvt_attn_fwd(ptr(qkv), None, ptr(O), ptr(lse), B, N, h, hd, scale, self.dti, st), "attn_fwd")
             else:
                 Pm, lse = self._attention_fwd_unfused(qkv, O, B, N, D, h, hd, scale, st), None
             wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
@@ -527,7 +527,7 @@ class Engine:
         gemm(qkv, qkv, S, dtype=self.dtype, M=N, N=N, K=hd, lda=3 * D, ldb=3 * D, ldc=N, batch=B * h, batch_inner=h,
              sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(h * N * N, N * N), b_off=D, alpha=scale, c_f32=True)
         Pm = self._empty(B * h, N, N)
-        check(lib.htrvt_softmax_rows(ptr(S), ptr(Pm), B * h * N, N, self.dti, st), "softmax_rows")
+        check(lib.htrvt_softmax_rows(ptr(S), ptr(Pm), B * h * N, N, self.dti, None, 0, st), "softmax_rows")
         del S
         gemm(Pm, qkv, O, dtype=self.dtype, M=N, N=hd, K=N, lda=N, ldb=3 * D, ldc=D, b_layout=MNMAJOR, batch=B * h,
              batch_inner=h, sA=(h * N * N, N * N), sB=(N * 3 * D, hd), sC=(N * D, hd), b_off=2 * D)
@@ -609,8 +609,8 @@ class Engine:
             dqkv = self._empty(M, 3 * D)
             if Pm is None:      # fused forward: recomputing fused backward (dQ launch, then dK/dV launch)
                 delta = self._empty(B * h, N, dtype=torch.float32)
-                check(lib.htrvt_attn_bwd(ptr(qkv), ptr(e["O"]), ptr(dO), ptr(e["lse"]), ptr(delta), ptr(dqkv), B, N, h, hd,
-                                         scale, self.dti, st), "attn_bwd")
+                check(lib.htrvt_attn_bwd(ptr(qkv), None, ptr(e["O"]), ptr(dO), ptr(e["lse"]), ptr(delta), ptr(dqkv), None,
+                                         B, N, h, hd, scale, self.dti, st), "attn_bwd")
             else:
                 self._attention_bwd_unfused(qkv, Pm, dO, dqkv, B, N, D, h, hd, scale, st)
             wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])

@@ -132,20 +132,27 @@ int htrvt_pool_tokens(const void* x, const float* keep, const float* mask_token,
 /* ---- encoder helpers (HTR_VT.py:27-39,68-83,169-170,236-239) ------------------ */
 int htrvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                         int64_t rows, int D, float eps, int dtype, void* stream);
-/* in-place row softmax of float32 scores [rows][n] -> probabilities of type dtype in `p` */
-int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, void* stream);
+/* row softmax of float32 scores [rows][n] -> probabilities of type dtype in `p`.  bias (may be NULL): float32
+ * [bias_rows][n] added to the scores first, score row r taking bias row r % bias_rows (rows ordered [batch][head][query]
+ * with bias_rows = heads * N: the relative-position / window bias of SURVEY 8(f-4)). */
+int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, const float* bias, int64_t bias_rows,
+                       void* stream);
 /* Fused multi-head self-attention, bfloat16 (HTR_VT.py:27-36: softmax(q k^T * scale) v and its autograd backward).
  * qkv [B*N][3][heads][hd] (the qkv Linear's output), out / dout [B*N][heads][hd], dqkv like qkv; scores and
  * probabilities stay on chip.  lse2 [B*heads][N] float32 (may be NULL in the forward when no backward follows):
  * log2 of the softmax denominator in the scaled base-2 domain, P = exp2(S * scale * log2(e) - lse2).
  * delta [B*heads][N] float32: scratch of the backward (rowsum(dout * out), written by its first launch).
  * htrvt_attn_supported: N a multiple of 128, hd in {32, 64, 128}, dtype bfloat16 (others: the htrvt_gemm +
- * htrvt_softmax_rows path). */
+ * htrvt_softmax_rows path).
+ * bias (may be NULL): float32 [heads][N][N] added to the scaled scores before the softmax -- the variant blocks of
+ * relative-position bias table gathered per (query, key) and, for 1-D windowed / shifted attention, a
+ * large negative number (-1e30, not -inf) outside the query's window (model_window/model/HTR_VT.py:23-56,113-154);
+ * dbias (may be NULL): float32 [heads][N][N] += sum over the batch of d(loss)/d(score) (float atomics). */
 int htrvt_attn_supported(int N, int hd, int dtype);
-int htrvt_attn_fwd(const void* qkv, void* out, float* lse2, int B, int N, int heads, int hd, float scale, int dtype,
-                   void* stream);
-int htrvt_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, float* delta, void* dqkv,
-                   int B, int N, int heads, int hd, float scale, int dtype, void* stream);
+int htrvt_attn_fwd(const void* qkv, const float* bias, void* out, float* lse2, int B, int N, int heads, int hd, float scale,
+                   int dtype, void* stream);
+int htrvt_attn_bwd(const void* qkv, const float* bias, const void* out, const void* dout, const float* lse2, float* delta,
+                   void* dqkv, float* dbias, int B, int N, int heads, int hd, float scale, int dtype, void* stream);
 /* param-free LN over all N*C logits of a sample (HTR_VT.py:136,239): in dtype -> out float32 */
 int htrvt_seq_whiten_fwd(const void* x, float* y, float* stats, int B, int NC, float eps, int dtype, void* stream);
 

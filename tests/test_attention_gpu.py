@@ -38,19 +38,19 @@ def _ref(qkv, B, N, h, hd, dout=None):
     return o.detach(), lse2.detach(), dqkv
 
 
-def _fwd(qkv, B, N, h, hd, want_lse=True):
+def _fwd(qkv, B, N, h, hd, want_lse=True, bias=None):
     lib, check, ptr, stream = _lib()
     out = torch.full((B * N, h * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
     lse = torch.full((B * h, N), float("nan"), dtype=torch.float32, device="cuda") if want_lse else None
-    check(lib.htrvt_attn_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, hd, hd ** -0.5, 1, stream()), "attn_fwd")
+    check(lib.htrvt_attn_fwd(ptr(qkv), ptr(bias), ptr(out), ptr(lse), B, N, h, hd, hd ** -0.5, 1, stream()), "attn_fwd")
     return out, lse
 
 
-def _bwd(qkv, out, dout, lse, B, N, h, hd):
+def _bwd(qkv, out, dout, lse, B, N, h, hd, bias=None, dbias=None):
     lib, check, ptr, stream = _lib()
     dqkv = torch.full((B * N, 3 * h * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
     delta = torch.empty(B * h, N, dtype=torch.float32, device="cuda")
-    check(lib.htrvt_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), B, N, h, hd, hd ** -0.5, 1,
+    check(lib.htrvt_attn_bwd(ptr(qkv), ptr(bias), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(dbias), B, N, h, hd, hd ** -0.5, 1,
                              stream()), "attn_bwd")
     return dqkv, delta
 

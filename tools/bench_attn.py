@@ -23,12 +23,13 @@ def run():
         lse = torch.empty(B * h, N, device="cuda")
         delta = torch.empty_like(lse)
         sc = hd ** -0.5
+        bias = dbias = None
 
         def fwd():
-            check(lib.htrvt_attn_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, hd, sc, 1, stream()), "f")
+            check(lib.htrvt_attn_fwd(ptr(qkv), ptr(bias), ptr(out), ptr(lse), B, N, h, hd, sc, 1, stream()), "f")
 
         def bwd():
-            check(lib.htrvt_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), B, N, h, hd, sc, 1, stream()), "b")
+            check(lib.htrvt_attn_bwd(ptr(qkv), ptr(bias), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(dbias), B, N, h, hd, sc, 1, stream()), "b")
 
         res = []
         for fn, flops, byts in ((fwd, 4.0 * B * h * N * N * hd, 2 * B * N * 4 * D), (bwd, 14.0 * B * h * N * N * hd, 2 * B * N * 12 * D)):

@@ -22,6 +22,8 @@
 //     written to LDS after them (one barrier per tile).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_common.h"
 
 using namespace htrvt;
@@ -55,6 +57,17 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1.  Element indices of the accumulator vectors are
+// constants from the start this way; with `#pragma unroll` loops whose body holds a store or an atomic the vectors were
+// indexed dynamically for a while and ended up in scratch memory.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // A operand (rows = 32 consecutive columns of the tile starting at 32*dt, k = 16 tile rows in accumulator-as-operand
 // order: element j of lane half h is tile row row0 + 16 s + 8 (j >> 2) + 4 h + (j & 3)) by two transposed reads
 template <int HD>
@@ -86,36 +99,36 @@ __device__ __forceinline__ bf16x8_t acc_frag(const f32x16_t& x, int s) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// staging of one [KT][HD] tile: global -> registers (issue) ... registers -> LDS (commit), NTH threads.
-// Free functions over a caller-owned register array (as members of a struct the array stayed in scratch memory).
+// staging of one [KT][HD] tile: global -> registers (issue) ... registers -> LDS (commit), NTH threads
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // a first-class 16-byte vector: HIP's uint4 is a struct whose
+                                                                    // copies are memcpys, which kept the staged tile in scratch
+                                                                    // memory whenever a store or an atomic sat in between
 template <int HD, int NTH>
 struct TileStage {
   static constexpr int CPR = HD / 8;                 // 16-byte chunks per row
   static constexpr int NL = KT * CPR / NTH;          // loads per thread
-  static_assert(KT * CPR % NTH == 0, "tile must divide over the threads");
+  static_assert(KT * CPR % NTH == 0 && NL >= 1 && NL <= 4, "tile must divide over the threads, at most 4 loads each");
+  u32x4_t r0, r1, r2, r3;
+
+  static __device__ __forceinline__ int row_of(int u) { return (threadIdx.x + NTH * u) / CPR; }
+  static __device__ __forceinline__ int ch_of(int u) { return (threadIdx.x + NTH * u) % CPR; }
+  static __device__ __forceinline__ u32x4_t ld16(const bf16_t* base, long long ld, int row, int ch) {
+    return *reinterpret_cast<const u32x4_t*>(base + (long long)row * ld + ch * 8);
+  }
+
+  __device__ __forceinline__ void issue(const bf16_t* base, long long ld, int row0) {
+    r0 = ld16(base, ld, row0 + row_of(0), ch_of(0));
+    if constexpr (NL > 1) r1 = ld16(base, ld, row0 + row_of(1), ch_of(1));
+    if constexpr (NL > 2) r2 = ld16(base, ld, row0 + row_of(2), ch_of(2));
+    if constexpr (NL > 3) r3 = ld16(base, ld, row0 + row_of(3), ch_of(3));
+  }
+  __device__ __forceinline__ void commit(char* tile) const {
+    *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(0), ch_of(0))) = r0;
+    if constexpr (NL > 1) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(1), ch_of(1))) = r1;
+    if constexpr (NL > 2) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(2), ch_of(2))) = r2;
+    if constexpr (NL > 3) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(3), ch_of(3))) = r3;
+  }
 };
-
-template <int HD, int NTH, int NL>
-__device__ __forceinline__ void stage_issue(uint4 (&reg)[NL], const bf16_t* base, long long ld, int row0) {
-  constexpr int CPR = HD / 8;
-  static_assert(NL == TileStage<HD, NTH>::NL, "register array size");
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int c = threadIdx.x + NTH * u, row = c / CPR, ch = c - row * CPR;
-    reg[u] = *reinterpret_cast<const uint4*>(base + (long long)(row0 + row) * ld + ch * 8);
-  }
-}
-
-template <int HD, int NTH, int NL>
-__device__ __forceinline__ void stage_commit(const uint4 (&reg)[NL], char* tile) {
-  constexpr int CPR = HD / 8;
-  static_assert(NL == TileStage<HD, NTH>::NL, "register array size");
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int c = threadIdx.x + NTH * u, row = c / CPR, ch = c - row * CPR;
-    *reinterpret_cast<uint4*>(tile + lds_off<HD>(row, ch)) = reg[u];
-  }
-}
 
 // v_exp_f32 directly: every argument here is <= ~0 (a score minus its row maximum / log-sum-exp), results below 2^-126
 // flush to zero, which is what a probability that small is worth; exp2f() would wrap the instruction in range scaling
@@ -173,11 +186,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   for (int s = 0; s < NS; ++s)
     qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)(q0 + r) * ld + 16 * s + 8 * hf));
 
-  uint4 sk[TileStage<HD, NTH>::NL], sv[TileStage<HD, NTH>::NL];
-  stage_issue<HD, NTH>(sk, kbase, ld, 0);
-  stage_issue<HD, NTH>(sv, vbase, ld, 0);
-  stage_commit<HD, NTH>(sk, smem);
-  stage_commit<HD, NTH>(sv, smem + TILE_B);
+  TileStage<HD, NTH> sk, sv;
+  sk.issue(kbase, ld, 0);
+  sv.issue(vbase, ld, 0);
+  sk.commit(smem);
+  sv.commit(smem + TILE_B);
   __syncthreads();
 
   f32x16_t o[ND];
@@ -196,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // loads, so the staging registers stay registers
     const int tn = min(t + 1, nt - 1);
     if constexpr (!(DBG & 1)) {
-      stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
-      stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+      sk.issue(kbase, ld, tn * KT);
+      sv.issue(vbase, ld, tn * KT);
     }
     // S^T tiles: keys 32 c .. 32 c + 31 of this tile x the wave's 32 queries
     f32x16_t st[2];
@@ -266,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         for (int d = 0; d < ND; ++d)
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vt, 32 * c, s, d, lane), pb, o[d], 0, 0, 0);
       }
-    stage_commit<HD, NTH>(sk, nxt);
-    stage_commit<HD, NTH>(sv, nxt + TILE_B);
+    sk.commit(nxt);
+    sv.commit(nxt + TILE_B);
     __syncthreads();
   }
 
@@ -324,11 +337,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
   const float lse = p.lse2[(long long)bh * p.N + q0 + r];
   if (hf == 0) delta[(long long)bh * p.N + q0 + r] = dl;
 
-  uint4 sk[TileStage<HD, NTH>::NL], sv[TileStage<HD, NTH>::NL];
-  stage_issue<HD, NTH>(sk, kbase, ld, 0);
-  stage_issue<HD, NTH>(sv, vbase, ld, 0);
-  stage_commit<HD, NTH>(sk, smem);
-  stage_commit<HD, NTH>(sv, smem + TILE_B);
+  TileStage<HD, NTH> sk, sv;
+  sk.issue(kbase, ld, 0);
+  sv.issue(vbase, ld, 0);
+  sk.commit(smem);
+  sv.commit(smem + TILE_B);
   __syncthreads();
 
   f32x16_t dq[ND];
@@ -343,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
     const char* vt = kt + TILE_B;
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE_B;
     const int tn = min(t + 1, nt - 1);
-    stage_issue<HD, NTH>(sk, kbase, ld, tn * KT);
-    stage_issue<HD, NTH>(sv, vbase, ld, tn * KT);
+    sk.issue(kbase, ld, tn * KT);
+    sv.issue(vbase, ld, tn * KT);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       f32x16_t st, dp;
@@ -381,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
           dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kt, 32 * c, s, d, lane), dsb, dq[d], 0, 0, 0);
       }
     }
-    stage_commit<HD, NTH>(sk, nxt);
-    stage_commit<HD, NTH>(sv, nxt + TILE_B);
+    sk.commit(nxt);
+    sv.commit(nxt + TILE_B);
     __syncthreads();
   }
   store_lane_rows<ND>(dq, p.dqkv + ((long long)b * p.N + q0 + r) * ld + hh * HD, hf, 1.0f);
@@ -399,7 +412,7 @@ template <int HD, bool BIAS = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p, const float* __restrict__ delta) {
   constexpr int NTH = 256, KB = 128;
   constexpr int TILE_B = KT * HD * 2;
-  constexpr int STAGE_B = 2 * TILE_B + 2 * KT * 4;     // Q tile | dO tile | lse2[KT] | delta[KT]
+  constexpr int STAGE_B = 2 * TILE_B + 2 * KT * 4 + 16;     // Q tile | dO tile | lse2[KT] | delta[KT] | dump word
   constexpr int NS = HD / 16, ND = HD / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -428,20 +441,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
     vf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
   }
 
-  uint4 sq[TileStage<HD, NTH>::NL], sd[TileStage<HD, NTH>::NL];
-  float sc = 0.f;   // thread < 64: lse2 of query tid; 64 <= thread < 128: delta of query tid - 64
-  auto issue_consts = [&](int row0) {
-    if (threadIdx.x < 2 * KT) sc = threadIdx.x < KT ? lsebase[row0 + threadIdx.x] : delbase[row0 + threadIdx.x - KT];
-  };
-  auto commit_consts = [&](char* stage) {
-    if (threadIdx.x < 2 * KT) reinterpret_cast<float*>(stage + 2 * TILE_B)[threadIdx.x] = sc;
-  };
-  stage_issue<HD, NTH>(sq, qbase, ld, 0);
-  stage_issue<HD, NTH>(sd, dobase, ldo, 0);
-  issue_consts(0);
-  stage_commit<HD, NTH>(sq, smem);
-  stage_commit<HD, NTH>(sd, smem + TILE_B);
-  commit_consts(smem);
+  TileStage<HD, NTH> sq, sd;
+  // thread < 64: lse2 of query tid of the staged tile; 64 <= thread < 128: delta of query tid - 64 (other threads
+  // re-read entry 0: no branch around the load)
+  const float* cbase = threadIdx.x < KT ? lsebase + threadIdx.x : (threadIdx.x < 2 * KT ? delbase + (threadIdx.x - KT) : lsebase);
+  const int cslot = threadIdx.x < 2 * KT ? threadIdx.x : 2 * KT;       // slot 2*KT: a dump word behind the two arrays
+  float sc;
+  sq.issue(qbase, ld, 0);
+  sd.issue(dobase, ldo, 0);
+  sc = cbase[0];
+  sq.commit(smem);
+  sd.commit(smem + TILE_B);
+  reinterpret_cast<float*>(smem + 2 * TILE_B)[cslot] = sc;
   __syncthreads();
 
   f32x16_t dk[ND], dv[ND];
@@ -457,9 +468,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
     const float* cst = reinterpret_cast<const float*>(qt + 2 * TILE_B);
     char* nxt = smem + ((t + 1) & 1) * STAGE_B;
     const int tn = min(t + 1, nt - 1);
-    stage_issue<HD, NTH>(sq, qbase, ld, tn * KT);
-    stage_issue<HD, NTH>(sd, dobase, ldo, tn * KT);
-    issue_consts(tn * KT);
+    sq.issue(qbase, ld, tn * KT);
+    sd.issue(dobase, ldo, tn * KT);
+    sc = cbase[tn * KT];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       f32x16_t st, dp;
@@ -471,27 +482,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dot, 32 * c, s, lane), vf[s], dp, 0, 0, 0);
       }
       // accumulator register i is query 32 c + (i & 3) + 8 (i >> 2) + 4 hf of the tile
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      static_for<0, 4>([&](auto G) {
+        constexpr int g = decltype(G)::value;
         const float4 ls = *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf);
         const float4 de = *reinterpret_cast<const float4*>(cst + KT + 32 * c + 8 * g + 4 * hf);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float sb = -(&ls.x)[j];
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+        static_for<0, 4>([&](auto J) {
+          constexpr int j = decltype(J)::value, i = 4 * g + j;
+          float sb = -lsv[j];
           long long boff = 0;
           if constexpr (BIAS) {     // bias[h][query][key]: lanes of a half are 32 consecutive keys of one query row
             boff = ((long long)hh * p.N + t * KT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
             sb = fmaf(p.bias[boff], LOG2E, sb);
           }
-          const float pr = fast_exp2(fmaf(st[4 * g + j], p.sl2, sb));
-          const float dsu = pr * (dp[4 * g + j] - (&de.x)[j]);              // d(score): gradient of the bias entry too
-          if constexpr (BIAS) {
-            if (p.dbias != nullptr) atomicAdd(p.dbias + boff, dsu);         // summed over the batch
+          const float pr = fast_exp2(fmaf(st[i], p.sl2, sb));
+          const float dsu = pr * (dp[i] - dev[j]);                          // d(score): gradient of the bias entry too
+          if constexpr (BIAS) {   // summed over the batch
+            typedef __attribute__((address_space(1))) float gfloat;
+            __hip_atomic_fetch_add((gfloat*)(p.dbias + boff), dsu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          st[4 * g + j] = pr;                                               // P
-          dp[4 * g + j] = dsu * p.scale;                                    // dS
-        }
-      }
+          st[i] = pr;                                                       // P
+          dp[i] = dsu * p.scale;                                            // dS
+        });
+      });
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8_t pb = acc_frag(st, s), dsb = acc_frag(dp, s);
@@ -502,9 +515,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
         }
       }
     }
-    stage_commit<HD, NTH>(sq, nxt);
-    stage_commit<HD, NTH>(sd, nxt + TILE_B);
-    commit_consts(nxt);
+    sq.commit(nxt);
+    sd.commit(nxt + TILE_B);
+    reinterpret_cast<float*>(nxt + 2 * TILE_B)[cslot] = sc;
     __syncthreads();
   }
   bf16_t* grow = p.dqkv + ((long long)b * p.N + k0 + r) * ld + hh * HD;
@@ -538,7 +551,7 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <int HD, bool BIAS>
 int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
   constexpr int smem_dq = 2 * 2 * KT * HD * 2;
-  constexpr int smem_kv = 2 * (2 * KT * HD * 2 + 2 * KT * 4);
+  constexpr int smem_kv = 2 * (2 * KT * HD * 2 + 2 * KT * 4 + 16);
   static bool attr_done = false;
   auto kq = attn_bwd_dq_kernel<HD, BIAS>;
   auto kkv = attn_bwd_dkv_kernel<HD, BIAS>;
@@ -601,7 +614,7 @@ extern "C" int htrvt_attn_bwd(const void* qkv, const float* bias, const void* ou
   p.B = B; p.N = N; p.h = heads;
   p.scale = scale;
   p.sl2 = scale * LOG2E;
-  HTRVT_REQUIRE(dbias == nullptr || bias != nullptr, "htrvt_attn_bwd: dbias without bias");
+  HTRVT_REQUIRE((dbias != nullptr) == (bias != nullptr), "htrvt_attn_bwd: bias and dbias go together (both or neither)");
   hipStream_t st = (hipStream_t)stream;
   if (bias != nullptr) {
     if (hd == 128) return launch_bwd<128, true>(p, delta, st);

@@ -147,7 +147,7 @@ int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, 
  * bias (may be NULL): float32 [heads][N][N] added to the scaled scores before the softmax -- the variant blocks of
  * relative-position bias table gathered per (query, key) and, for 1-D windowed / shifted attention, a
  * large negative number (-1e30, not -inf) outside the query's window (model_window/model/HTR_VT.py:23-56,113-154);
- * dbias (may be NULL): float32 [heads][N][N] += sum over the batch of d(loss)/d(score) (float atomics). */
+ * dbias (NULL exactly when bias is NULL): float32 [heads][N][N] += sum over the batch of d(loss)/d(score) (float atomics). */
 int htrvt_attn_supported(int N, int hd, int dtype);
 int htrvt_attn_fwd(const void* qkv, const float* bias, void* out, float* lse2, int B, int N, int heads, int hd, float scale,
                    int dtype, void* stream);

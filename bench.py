@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
+    ap.add_argument("--deterministic", action="store_true", help="A/B: split-K weight gradients through ordered slabs instead "
+                    "of float atomics also on the bf16 path (the float32 path always does)")
+    ap.add_argument("--no-fused-attention", action="store_true", help="A/B: batched GEMMs + row softmax instead of csrc/attention.hip")
     ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU iterations (about 10 s of host work in total)")
@@ -161,6 +164,8 @@ def main():
         tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world, use_collectives=use_dist)
         tr.engine.fuse_bn_backward = not args.no_fuse_bn
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
+        tr.engine.deterministic = tr.engine.deterministic or args.deterministic
+        tr.engine.fused_attention = not args.no_fused_attention
 
         if args.sam:
             from htrvt_amd.ema import ModelEma

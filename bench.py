@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--deterministic", action="store_true", help="A/B: split-K weight gradients through ordered slabs instead "
                     "of float atomics also on the bf16 path (the float32 path always does)")
+    ap.add_argument("--parallel-classes", action="store_true", help="A/B: parity-class dgrad launches of a strided conv on separate streams")
     ap.add_argument("--no-fused-attention", action="store_true", help="A/B: batched GEMMs + row softmax instead of csrc/attention.hip")
     ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -166,6 +167,7 @@ def main():
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
         tr.engine.deterministic = tr.engine.deterministic or args.deterministic
         tr.engine.fused_attention = not args.no_fused_attention
+        tr.engine.parallel_classes = args.parallel_classes
 
         if args.sam:
             from htrvt_amd.ema import ModelEma

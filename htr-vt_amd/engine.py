@@ -74,6 +74,10 @@ class Engine:
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
         self.fused_attention = True    # bf16: one launch per direction, scores / probabilities never reach HBM (csrc/attention.hip)
+        # strided conv dgrad = one launch per input-pixel parity class: independent launches (disjoint output pixels), so
+        # they may run on separate streams -- an epilogue-only class (no tap reaches it) then overlaps an MFMA-heavy one
+        self.parallel_classes = False
+        self._cls_streams = None
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
@@ -277,15 +281,28 @@ class Engine:
         if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
             tile0 = 0
+            par = self.parallel_classes and ops.PROFILE is None
+            main = torch.cuda.current_stream()
+            if par and self._cls_streams is None:
+                self._cls_streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+            used = []
             for a in range(g.sh):
                 for b in range(g.sw):
                     nt = sum(1 for dy_ in range(g.kh) if (a + g.ph - dy_) % g.sh == 0) * \
                          sum(1 for dx_ in range(g.kw) if (b + g.pw - dx_) % g.sw == 0)
                     Hq, Wq = (g.Hi - a + g.sh - 1) // g.sh, (g.Wi - b + g.sw - 1) // g.sw
-                    gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
-                         ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b),
-                         relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, tile=4 if (relu_src is not None or bnb) else 0)
+                    idx = a * g.sw + b
+                    st_ = self._cls_streams[idx - 1] if (par and idx > 0) else main
+                    if st_ is not main:
+                        st_.wait_stream(main)
+                        used.append(st_)
+                    with torch.cuda.stream(st_):
+                        gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
+                             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b),
+                             relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, tile=4 if (relu_src is not None or bnb) else 0)
                     tile0 += ops.gemm_num_mtiles(g.B * Hq * Wq, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
+            for st_ in used:       # every class has written its pixels before anything downstream reads dx
+                main.wait_stream(st_)
             return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb)

@@ -32,6 +32,31 @@ with torch.no_grad():
     ema.ema._engines.clear()
     y2 = ema.ema(xd)
     print("after clearing engines vs fresh:", float((y2 - yf).abs().max()), " vs y1:", float((y2 - y1).abs().max()))
+    sa, sb = ema.ema.state_dict(), fresh.state_dict()
+    for k in sa:
+        if not torch.equal(sa[k], sb[k]):
+            print("state differs:", k, sa[k].dtype, float((sa[k].double() - sb[k].double()).abs().max()))
+    print("training flags:", ema.ema.training, fresh.training, {type(mm).__name__ for mm in ema.ema.modules() if mm.training}, {type(mm).__name__ for mm in fresh.modules() if mm.training})
+    # activations stage by stage through the two engines
+    Pa = dict(ema.ema.state_dict(keep_vars=True)); Pb = dict(fresh.state_dict(keep_vars=True))
+    ea, eb = ema.ema._engine(xd.device), fresh._engine(xd.device)
+    ya = ea.forward(Pa, xd, train=False, save=True); sva = ea.saved
+    yb = eb.forward(Pb, xd, train=False, save=True); svb = eb.saved
+    print("engine.forward(save=True) diff:", float((ya - yb).abs().max()))
+    def cmp(tag, u, v):
+        if isinstance(u, torch.Tensor) and isinstance(v, torch.Tensor) and u.shape == v.shape:
+            d = float((u.double() - v.double()).abs().max())
+            if d > 0: print("  act differs:", tag, d)
+    for k in sva:
+        if isinstance(sva[k], torch.Tensor): cmp(k, sva[k], svb[k])
+    for i, (ba, bb) in enumerate(zip(sva["stem_blocks"], svb["stem_blocks"])):
+        for k in ba:
+            if isinstance(ba[k], torch.Tensor): cmp(f"blk{i}.{k}", ba[k], bb[k])
+            if isinstance(ba[k], tuple):
+                for j, (u, v) in enumerate(zip(ba[k], bb[k])): cmp(f"blk{i}.{k}[{j}]", u, v)
+    for i, (ba, bb) in enumerate(zip(sva["enc"], svb["enc"])):
+        for k in ba:
+            if isinstance(ba[k], torch.Tensor): cmp(f"enc{i}.{k}", ba[k], bb[k])
     eng = fresh._engine(xd.device)
     # which stage differs first: compare packed weights
     e1 = ema.ema._engine(xd.device)

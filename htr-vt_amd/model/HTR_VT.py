@@ -80,10 +80,12 @@ class _HTRVTFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward and backward are HIP kernel sequences."""
 
     @staticmethod
-    def forward(ctx, module, img, keep, train, names, *tensors):
+    def forward(ctx, module, img, keep, train, need, names, *tensors):
         eng = module._engine(img.device)
         P = dict(zip(names, tensors))
-        need = any(ctx.needs_input_grad)     # False under torch.no_grad()
+        # need: grad mode was on at the call and some parameter requires grad (decided by the caller: inside forward() grad
+        # mode is always off, and ctx.needs_input_grad stays True under torch.no_grad() -- a no_grad validation pass of
+        # the training model would otherwise keep 13 GB of activations and miss the fused eval path)
         y = eng.forward(P, img, keep_mask=keep, train=train, save=need)
         if need:
             ctx.saved_acts, eng.saved = eng.saved, None
@@ -97,7 +99,7 @@ class _HTRVTFunction(torch.autograd.Function):
         eng.saved = ctx.saved_acts
         eng.backward(P, G, dy.contiguous().float())
         ctx.saved_acts = None
-        return (None, None, None, None, None) + tuple(G.get(n) for n in names)
+        return (None, None, None, None, None, None) + tuple(G.get(n) for n in names)
 
 
 class MaskedAutoencoderViT(nn.Module):
@@ -170,7 +172,8 @@ class MaskedAutoencoderViT(nn.Module):
             tensors.append(t)
         # uint8 images (the data pipeline's raw grey levels) stay uint8: the first kernels read them as value / 255
         x = x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float()
-        return _HTRVTFunction.apply(self, x, keep_mask, self.training, tuple(names), *tensors)
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+        return _HTRVTFunction.apply(self, x, keep_mask, self.training, need, tuple(names), *tensors)
 
 
 def create_model(nb_cls, img_size, **kwargs):

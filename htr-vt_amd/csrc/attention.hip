@@ -103,17 +103,20 @@ __device__ __forceinline__ bf16x8_t acc_frag(const f32x16_t& x, int s) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // a first-class 16-byte vector: HIP's uint4 is a struct whose
                                                                     // copies are memcpys, which kept the staged tile in scratch
                                                                     // memory whenever a store or an atomic sat in between
-template <int HD, int NTH>
+template <int HD, int NTH, int ROWS = KT>
 struct TileStage {
   static constexpr int CPR = HD / 8;                 // 16-byte chunks per row
-  static constexpr int NL = KT * CPR / NTH;          // loads per thread
-  static_assert(KT * CPR % NTH == 0 && NL >= 1 && NL <= 4, "tile must divide over the threads, at most 4 loads each");
-  u32x4_t r0, r1, r2, r3;
+  static constexpr int NL = ROWS * CPR / NTH;        // loads per thread
+  static_assert(ROWS * CPR % NTH == 0 && NL >= 1 && NL <= 8, "tile must divide over the threads, at most 8 loads each");
+  u32x4_t r0, r1, r2, r3, r4, r5, r6, r7;
 
   static __device__ __forceinline__ int row_of(int u) { return (threadIdx.x + NTH * u) / CPR; }
   static __device__ __forceinline__ int ch_of(int u) { return (threadIdx.x + NTH * u) % CPR; }
   static __device__ __forceinline__ u32x4_t ld16(const bf16_t* base, long long ld, int row, int ch) {
     return *reinterpret_cast<const u32x4_t*>(base + (long long)row * ld + ch * 8);
+  }
+  static __device__ __forceinline__ void st16(char* tile, int u, const u32x4_t& v) {
+    *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(u), ch_of(u))) = v;
   }
 
   __device__ __forceinline__ void issue(const bf16_t* base, long long ld, int row0) {
@@ -121,12 +124,20 @@ struct TileStage {
     if constexpr (NL > 1) r1 = ld16(base, ld, row0 + row_of(1), ch_of(1));
     if constexpr (NL > 2) r2 = ld16(base, ld, row0 + row_of(2), ch_of(2));
     if constexpr (NL > 3) r3 = ld16(base, ld, row0 + row_of(3), ch_of(3));
+    if constexpr (NL > 4) r4 = ld16(base, ld, row0 + row_of(4), ch_of(4));
+    if constexpr (NL > 5) r5 = ld16(base, ld, row0 + row_of(5), ch_of(5));
+    if constexpr (NL > 6) r6 = ld16(base, ld, row0 + row_of(6), ch_of(6));
+    if constexpr (NL > 7) r7 = ld16(base, ld, row0 + row_of(7), ch_of(7));
   }
   __device__ __forceinline__ void commit(char* tile) const {
-    *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(0), ch_of(0))) = r0;
-    if constexpr (NL > 1) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(1), ch_of(1))) = r1;
-    if constexpr (NL > 2) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(2), ch_of(2))) = r2;
-    if constexpr (NL > 3) *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(3), ch_of(3))) = r3;
+    st16(tile, 0, r0);
+    if constexpr (NL > 1) st16(tile, 1, r1);
+    if constexpr (NL > 2) st16(tile, 2, r2);
+    if constexpr (NL > 3) st16(tile, 3, r3);
+    if constexpr (NL > 4) st16(tile, 4, r4);
+    if constexpr (NL > 5) st16(tile, 5, r5);
+    if constexpr (NL > 6) st16(tile, 6, r6);
+    if constexpr (NL > 7) st16(tile, 7, r7);
   }
 };
 
@@ -410,9 +421,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
 // -------------------------------------------------------------------------------------------------------------------
 template <int HD, bool BIAS = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p, const float* __restrict__ delta) {
-  constexpr int NTH = 256, KB = 128;
-  constexpr int TILE_B = KT * HD * 2;
-  constexpr int STAGE_B = 2 * TILE_B + 2 * KT * 4 + 16;     // Q tile | dO tile | lse2[KT] | delta[KT] | dump word
+  // 128-query tiles here (the forward / dQ kernels stage 64 keys): one workgroup per CU leaves 160 KB of LDS, and at
+  // N = 256 the whole pass is two tiles -- the second one in flight under the first one's 128 MFMAs per wave
+  constexpr int NTH = 256, KB = 128, QT = 128;
+  constexpr int TILE_B = QT * HD * 2;
+  constexpr int STAGE_B = 2 * TILE_B + 2 * QT * 4 + 16;     // Q tile | dO tile | lse2[QT] | delta[QT] | dump word
   constexpr int NS = HD / 16, ND = HD / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -441,11 +454,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
     vf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
   }
 
-  TileStage<HD, NTH> sq, sd;
+  TileStage<HD, NTH, QT> sq, sd;
   // thread < 64: lse2 of query tid of the staged tile; 64 <= thread < 128: delta of query tid - 64 (other threads
   // re-read entry 0: no branch around the load)
-  const float* cbase = threadIdx.x < KT ? lsebase + threadIdx.x : (threadIdx.x < 2 * KT ? delbase + (threadIdx.x - KT) : lsebase);
-  const int cslot = threadIdx.x < 2 * KT ? threadIdx.x : 2 * KT;       // slot 2*KT: a dump word behind the two arrays
+  const float* cbase = threadIdx.x < QT ? lsebase + threadIdx.x : (threadIdx.x < 2 * QT ? delbase + (threadIdx.x - QT) : lsebase);
+  const int cslot = threadIdx.x < 2 * QT ? threadIdx.x : 2 * QT;       // slot 2*QT: a dump word behind the two arrays
   float sc;
   sq.issue(qbase, ld, 0);
   sd.issue(dobase, ldo, 0);
@@ -461,18 +474,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
     for (int i = 0; i < 16; ++i) dk[d][i] = dv[d][i] = 0.f;
 
-  const int nt = p.N / KT;
+  const int nt = p.N / QT;
   for (int t = 0; t < nt; ++t) {
     const char* qt = smem + (t & 1) * STAGE_B;
     const char* dot = qt + TILE_B;
     const float* cst = reinterpret_cast<const float*>(qt + 2 * TILE_B);
     char* nxt = smem + ((t + 1) & 1) * STAGE_B;
     const int tn = min(t + 1, nt - 1);
-    sq.issue(qbase, ld, tn * KT);
-    sd.issue(dobase, ldo, tn * KT);
-    sc = cbase[tn * KT];
+    sq.issue(qbase, ld, tn * QT);
+    sd.issue(dobase, ldo, tn * QT);
+    sc = cbase[tn * QT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < QT / 32; ++c) {
       f32x16_t st, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
@@ -485,14 +498,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
       static_for<0, 4>([&](auto G) {
         constexpr int g = decltype(G)::value;
         const float4 ls = *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf);
-        const float4 de = *reinterpret_cast<const float4*>(cst + KT + 32 * c + 8 * g + 4 * hf);
+        const float4 de = *reinterpret_cast<const float4*>(cst + QT + 32 * c + 8 * g + 4 * hf);
         const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
         static_for<0, 4>([&](auto J) {
           constexpr int j = decltype(J)::value, i = 4 * g + j;
           float sb = -lsv[j];
           long long boff = 0;
           if constexpr (BIAS) {     // bias[h][query][key]: lanes of a half are 32 consecutive keys of one query row
-            boff = ((long long)hh * p.N + t * KT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
+            boff = ((long long)hh * p.N + t * QT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
             sb = fmaf(p.bias[boff], LOG2E, sb);
           }
           const float pr = fast_exp2(fmaf(st[i], p.sl2, sb));
@@ -551,7 +564,7 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <int HD, bool BIAS>
 int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
   constexpr int smem_dq = 2 * 2 * KT * HD * 2;
-  constexpr int smem_kv = 2 * (2 * KT * HD * 2 + 2 * KT * 4 + 16);
+  constexpr int smem_kv = 2 * (2 * 128 * HD * 2 + 2 * 128 * 4 + 16);
   static bool attr_done = false;
   auto kq = attn_bwd_dq_kernel<HD, BIAS>;
   auto kkv = attn_bwd_dkv_kernel<HD, BIAS>;

@@ -78,6 +78,10 @@ class Engine:
         # they may run on separate streams -- an epilogue-only class (no tap reaches it) then overlaps an MFMA-heavy one
         self.parallel_classes = False
         self._cls_streams = None
+        # training steps rewrite every weight: re-pack / re-cast all of them on the side stream at the start of the forward,
+        # under the (HBM-bound) image statistics, conv1 and max-pool kernels, instead of ~30 latency-bound launches in
+        # front of their first use
+        self.prefetch_packs = True
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
@@ -417,6 +421,21 @@ class Engine:
         if keep_mask is not None:   # uploaded before anything is enqueued: a pageable host->device copy waits for the stream
             keep = keep_mask.to(device=self.dev, dtype=torch.float32).contiguous()
 
+        prefetched = False
+        if self.prefetch_packs and self.dtype == torch.bfloat16:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_stream(torch.cuda.current_stream())     # behind whatever wrote the weights (the optimizer step)
+            with torch.cuda.stream(self._side):
+                for name, _ci, _co, _k, _st, _pd in s.stem_convs():
+                    self._conv_w(name, P[name + ".weight"])
+                for name in s.linears():
+                    if name == "head":
+                        self._head_w(P["head.weight"])
+                    else:
+                        self._lin_w(name, P[name + ".weight"])
+            prefetched = True
+
         # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
         stats = self._empty(B, 2, dtype=torch.float32)
         check(lib.htrvt_img_stats(ptr(img), ptr(stats), B, H * W, WHITEN_EPS, u8, st), "img_stats")
@@ -432,6 +451,9 @@ class Engine:
               "bn_relu_maxpool")
         if save:
             sv["img"], sv["stats"], sv["c1"], sv["bn1"], sv["idx"] = img, stats, c1, (sc, sf, mean, rstd), idx
+
+        if prefetched:
+            torch.cuda.current_stream().wait_stream(self._side)
 
         # --- residual stages (resnet18.py:79-81, 23-39) ---
         x = a

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--sam", action="store_true", help="the reference's full iteration (train.py:119-128): SAM(AdamW) = two "
                     "fwd+bwd passes + climb/restore + AdamW + ModelEma update; images/s counts each image once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-path", action="store_true", help="skip the short float32 parity-path timing beside the bf16 line")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--deterministic", action="store_true", help="A/B: split-K weight gradients through ordered slabs instead "
@@ -94,6 +95,28 @@ def cpu_baseline(args, mask):
             "sample": f"{args.cpu_iters} timed iterations (1 warm-up) of batch {args.cpu_batch} 64x{args.width}, "
                       f"{'eval forward + log_softmax' if args.forward_only else 'fwd+CTC+bwd (torch autograd over the oracle)'}"
                       f", torch CPU float32, {cores} threads"}
+
+
+def parity_path(args, dev, x, tg, tl, keep):
+    """the same training step on the float32 parity path (f32-input MFMA, bitwise-reproducible reductions) -- the path
+    that meets the 1e-3 logit gate of BASELINE.json -- timed briefly beside the bf16 headline so that the driver's
+    record carries both; reported, not part of `value`"""
+    from htrvt_amd.model import HTR_VT
+    from htrvt_amd.trainer import Trainer
+    torch.manual_seed(123)
+    model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=torch.float32).to(dev).train()
+    tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=False)
+    steps = 3
+    tr.step(x, tg, tl, keep_mask=keep)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x, tg, tl, keep_mask=keep)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"dtype": "f32", "ms_per_step": round(dt * 1e3, 2), "value": round(x.shape[0] / dt, 1), "unit": "line-images/s",
+            "steps": steps, "loss": float(loss.item()),
+            "note": "float32 parity path (logits within 1e-3 of the reference, tests/test_full_shape_gpu.py), same step and batch"}
 
 
 def spawn_ranks(n):
@@ -276,6 +299,9 @@ def main():
                           "tokens_per_image": N, "mask": "span 0.4/8 (run/iam.sh)", "parallelism": f"dp{world}",
                           "loss": float(loss.mean().item()) if loss is not None else None},
                "roofline": roof}
+        if (not args.no_parity_path and world == 1 and args.dtype == "bf16" and not args.forward_only and not args.sam
+                and args.scaling == "weak"):
+            out["parity_path"] = parity_path(args, dev, x, tg, tl, keep)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, keep)
         elif not args.no_cpu_baseline:

@@ -68,23 +68,46 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// Per-lane address constants of the two fragment reads.  lds_off's XOR term depends only on the low four bits of the tile
+// row, which are lane bits in both reads (row0 is a multiple of 32, 16 s a multiple of 16), and the chunk index is a
+// compile-time part OR-ed with a lane part on disjoint bits -- so every fragment address is
+//     (lane constant) XOR (compile-time constant) + (compile-time constant),
+// one v_xor per distinct (s) / (dt) instead of the full shift / mask / xor chain per read (the kernels are VALU-bound
+// beside their MFMAs).  tools/lds_bank_check.py checks these forms against lds_off for every lane.
+template <int HD>
+struct LaneAddr {
+  int rowb;        // row read:  lds_off(row0 + r, 2 s + h)              = (rowb ^ 32 s) + ROWB row0
+  int trb0, trb1;  // transposed: lds_off(row0 + 16 s + 4 h + q [+ 8], 4 dt + 2 g + (p >> 1)) + 8 (p & 1)
+                   //                                                    = (trb ^ 64 dt) + ROWB (row0 + 16 s)
+};
+
+template <int HD>
+__device__ __forceinline__ LaneAddr<HD> lane_addr(int lane) {
+  const int h = lane >> 5, g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+  LaneAddr<HD> la;
+  la.rowb = lds_off<HD>(lane & 31, h);
+  la.trb0 = lds_off<HD>(4 * h + q, 2 * g + (p >> 1)) + 8 * (p & 1);
+  la.trb1 = lds_off<HD>(4 * h + q + 8, 2 * g + (p >> 1)) + 8 * (p & 1);
+  return la;
+}
+
 // A operand (rows = 32 consecutive columns of the tile starting at 32*dt, k = 16 tile rows in accumulator-as-operand
 // order: element j of lane half h is tile row row0 + 16 s + 8 (j >> 2) + 4 h + (j & 3)) by two transposed reads
 template <int HD>
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int s, int dt, int lane) {
-  const int h = lane >> 5, g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
-  const int row = row0 + 16 * s + 4 * h + q;
-  const int c = 4 * dt + 2 * g + (p >> 1);
-  const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + lds_off<HD>(row, c) + 8 * (p & 1)));
-  const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + lds_off<HD>(row + 8, c) + 8 * (p & 1)));
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, const LaneAddr<HD>& la, int row0, int s, int dt) {
+  constexpr int ROWB = HD * 2;
+  const int add = ROWB * (row0 + 16 * s);
+  const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + ((la.trb0 ^ (64 * dt)) + add)));
+  const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(tile + ((la.trb1 ^ (64 * dt)) + add)));
   const s16x8_t r = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
 // row operand: lane (r = lane & 31, h = lane >> 5) takes elements 16 s + 8 h .. + 7 of tile row row0 + r
 template <int HD>
-__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row0, int s, int lane) {
-  const uint4 v = *reinterpret_cast<const uint4*>(tile + lds_off<HD>(row0 + (lane & 31), 2 * s + (lane >> 5)));
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, const LaneAddr<HD>& la, int row0, int s) {
+  constexpr int ROWB = HD * 2;
+  const uint4 v = *reinterpret_cast<const uint4*>(tile + ((la.rowb ^ (32 * s)) + ROWB * row0));
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
@@ -189,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hf = lane >> 5;
+  const LaneAddr<HD> la = lane_addr<HD>(lane);
   const int q0 = qb * QB + wave * 32;
 
   // Q^T as the B operand of S^T = K Q^T: lane (r, hf) holds Q[q0 + r][16 s + 8 hf .. + 7]
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
       for (int i = 0; i < 16; ++i) st[c][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s)
-        st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st[c], 0, 0, 0);
+        st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, la, 32 * c, s), qf[s], st[c], 0, 0, 0);
     }
     // online softmax for query r: this lane holds 32 of the tile's 64 keys, lane ^ 32 the other 32
     if constexpr (!(DBG & 2)) {
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const bf16x8_t pb = acc_frag(st[c], s);
 #pragma unroll
         for (int d = 0; d < ND; ++d)
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vt, 32 * c, s, d, lane), pb, o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vt, la, 32 * c, s, d), pb, o[d], 0, 0, 0);
       }
     sk.commit(nxt);
     sv.commit(nxt + TILE_B);
@@ -326,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hf = lane >> 5;
+  const LaneAddr<HD> la = lane_addr<HD>(lane);
   const int q0 = qb * QB + wave * 32;
 
   bf16x8_t qf[NS], dof[NS];
@@ -376,8 +401,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
       for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, 32 * c, s, lane), qf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vt, 32 * c, s, lane), dof[s], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, la, 32 * c, s), qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vt, la, 32 * c, s), dof[s], dp, 0, 0, 0);
       }
       if constexpr (BIAS) {
         const float* brow = p.bias + ((long long)hh * p.N + q0 + r) * p.N + t * KT + 32 * c + 4 * hf;
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
         const bf16x8_t dsb = acc_frag(st, s);
 #pragma unroll
         for (int d = 0; d < ND; ++d)
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kt, 32 * c, s, d, lane), dsb, dq[d], 0, 0, 0);
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kt, la, 32 * c, s, d), dsb, dq[d], 0, 0, 0);
       }
     }
     sk.commit(nxt);
@@ -423,7 +448,7 @@ template <int HD, bool BIAS = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p, const float* __restrict__ delta) {
   // 128-query tiles here (the forward / dQ kernels stage 64 keys): one workgroup per CU leaves 160 KB of LDS, and at
   // N = 256 the whole pass is two tiles -- the second one in flight under the first one's 128 MFMAs per wave
-  constexpr int NTH = 256, KB = 128, QT = 128;
+  constexpr int NTH = 256, KB = 128, QT = HD >= 128 ? 64 : 128;   // measured: 128-query tiles pay at hd 64 (286 vs 328 us), not at hd 128 (254 vs 244)
   constexpr int TILE_B = QT * HD * 2;
   constexpr int STAGE_B = 2 * TILE_B + 2 * QT * 4 + 16;     // Q tile | dO tile | lse2[QT] | delta[QT] | dump word
   constexpr int NS = HD / 16, ND = HD / 32;
@@ -445,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hf = lane >> 5;
+  const LaneAddr<HD> la = lane_addr<HD>(lane);
   const int k0 = kb * KB + wave * 32;
 
   bf16x8_t kf[NS], vf[NS];
@@ -491,8 +517,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
       for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qt, 32 * c, s, lane), kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dot, 32 * c, s, lane), vf[s], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qt, la, 32 * c, s), kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dot, la, 32 * c, s), vf[s], dp, 0, 0, 0);
       }
       // accumulator register i is query 32 c + (i & 3) + 8 (i >> 2) + 4 hf of the tile
       static_for<0, 4>([&](auto G) {
@@ -523,8 +549,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
         const bf16x8_t pb = acc_frag(st, s), dsb = acc_frag(dp, s);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dot, 32 * c, s, d, lane), pb, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qt, 32 * c, s, d, lane), dsb, dk[d], 0, 0, 0);
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dot, la, 32 * c, s, d), pb, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qt, la, 32 * c, s, d), dsb, dk[d], 0, 0, 0);
         }
       }
     }
@@ -564,7 +590,8 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <int HD, bool BIAS>
 int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
   constexpr int smem_dq = 2 * 2 * KT * HD * 2;
-  constexpr int smem_kv = 2 * (2 * 128 * HD * 2 + 2 * 128 * 4 + 16);
+  constexpr int QT = HD >= 128 ? 64 : 128;
+  constexpr int smem_kv = 2 * (2 * QT * HD * 2 + 2 * QT * 4 + 16);
   static bool attr_done = false;
   auto kq = attn_bwd_dq_kernel<HD, BIAS>;
   auto kkv = attn_bwd_dkv_kernel<HD, BIAS>;

@@ -29,8 +29,14 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
   r.v = __builtin_bit_cast(unsigned short, b);
   return r;
 }
+// two floats -> one dword of two bfloat16 (RNE, NaN stays NaN).  As a VECTOR conversion: hipcc then emits ONE
+// v_cvt_pk_bf16_f32; converting the halves separately and OR-ing them costs four instructions (two conversions with a
+// zero partner, a shift, an SDWA or) -- and every bf16 epilogue in this library is VALU work beside its stores.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_raw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)from_f32<bf16_t>(lo).v | ((unsigned)from_f32<bf16_t>(hi).v << 16);
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_raw_t));
 }
 
 // pixel i of an image batch that is float32, or uint8 taken as value / 255 (torchvision ToTensor: the uint8 -> float

@@ -6,7 +6,7 @@
 OUT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}/gpurun_out/$1
 shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-BENCH="$ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap-wgrad $*"
+BENCH="$ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-path --no-overlap-wgrad $*"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...

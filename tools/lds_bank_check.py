@@ -60,6 +60,27 @@ def tr_read(hd, row0, s, dt, second):
     return out
 
 
+def lane_forms_ok(hd):
+    """the per-lane XOR forms of csrc/attention.hip (LaneAddr) against off() for every lane and compile-time index"""
+    rowb_ = hd * 2
+    for lane in range(64):
+        h, g, i = lane >> 5, (lane >> 4) & 1, lane & 15
+        q, p = i >> 2, i & 3
+        rowb = off(hd, lane & 31, h)
+        trb = [off(hd, 4 * h + q + 8 * sec, 2 * g + (p >> 1)) + 8 * (p & 1) for sec in (0, 1)]
+        for row0 in (0, 32, 64, 96):
+            for s in range(hd // 16):
+                if (rowb ^ (32 * s)) + rowb_ * row0 != off(hd, row0 + (lane & 31), 2 * s + h):
+                    return False
+            for s in range(2):
+                for dt in range(hd // 32):
+                    for sec in (0, 1):
+                        want = off(hd, row0 + 16 * s + 4 * h + q + 8 * sec, 4 * dt + 2 * g + (p >> 1)) + 8 * (p & 1)
+                        if (trb[sec] ^ (64 * dt)) + rowb_ * (row0 + 16 * s) != want:
+                            return False
+    return True
+
+
 def main():
     ok = True
     for hd in (128, 64, 32):
@@ -69,8 +90,10 @@ def main():
         # the image must be a bijection of the tile's bytes
         seen = {off(hd, r, c) for r in range(64) for c in range(hd // 8)}
         bij = len(seen) == 64 * (hd // 8) and max(seen) == 64 * hd * 2 - 16
-        print(f"hd {hd:3d}: ds_read_b128 rows {worst_row}-way, ds_read_b64_tr_b16 {worst_tr}-way, bijective {bij}")
-        ok &= bij
+        forms = lane_forms_ok(hd)
+        print(f"hd {hd:3d}: ds_read_b128 rows {worst_row}-way, ds_read_b64_tr_b16 {worst_tr}-way, bijective {bij}, "
+              f"lane XOR forms == lds_off: {forms}")
+        ok &= bij and forms
     return 0 if ok else 1
 
 

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- first: libhtrvt_hip.so must bind to the HIP runtime PyTorch-ROCm already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhtrvt_hip.so")
+LIB_PATH = os.environ.get("HTRVT_LIB") or os.path.join(_HERE, "lib", "libhtrvt_hip.so")   # HTRVT_LIB: A/B builds of the library
 
 F32, BF16 = 0, 1
 KMAJOR, MNMAJOR = 0, 1

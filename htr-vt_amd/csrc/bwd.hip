@@ -318,15 +318,24 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
 }
 
 // pass B: dx = cA*g + cB*x + cC ; optionally also writes g (the ReLU-masked incoming gradient)
+// The 3 C coefficients sit in LDS (per element loads from global were 24 of the 27 loads of a vector) and the channel
+// index of a thread's vector advances by a constant per grid stride (no 64-bit modulo per vector).
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ yact,
                                                           const T* __restrict__ x, const float* __restrict__ coef,
                                                           T* __restrict__ dx, T* __restrict__ gout, long long nvec,
                                                           int C) {
   constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sco[];   // [3][C]
+  for (int k = threadIdx.x; k < 3 * C; k += NT) sco[k] = coef[k];
+  __syncthreads();
   const int cvec = C / CH;
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long long)gridDim.x * NT) {
-    const int c0 = (int)(i % cvec) * CH;
+  const long long stride = (long long)gridDim.x * NT;
+  const int step = (int)(stride % cvec);
+  long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  int cv = (int)(i % cvec);
+  for (; i < nvec; i += stride) {
+    const float* ca = sco + cv * CH;
     Vec16<T> vd, vx, vy, o, go;
     vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dy)[i];
     vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
@@ -336,10 +345,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
       float g = vd.get(j);
       if (yact && !(vy.get(j) > 0.f)) g = 0.f;
       go.set(j, g);
-      o.set(j, fmaf(coef[c0 + j], g, fmaf(coef[C + c0 + j], vx.get(j), coef[2 * C + c0 + j])));
+      o.set(j, fmaf(ca[j], g, fmaf(ca[C + j], vx.get(j), ca[2 * C + j])));
     }
     reinterpret_cast<decltype(o.raw)*>(dx)[i] = o.raw;
     if (gout) reinterpret_cast<decltype(go.raw)*>(gout)[i] = go.raw;
+    cv += step;
+    if (cv >= cvec) cv -= cvec;
   }
 }
 
@@ -809,7 +820,7 @@ extern "C" int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* 
   HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_bwd_apply: C=%d unsupported", C);
   const long long nvec = npix * (C / ch);
   dim3 grid(grid_for(nvec));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(NT), (size_t)3 * C * sizeof(float), (hipStream_t)stream, (const T*)dy,
                                        (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
   return check_launch("bn_bwd_apply");
 }

@@ -35,6 +35,9 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_raw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#ifdef HTRVT_EXP_OLDPACK   // A/B build of the former four-instruction form (tools: make EXTRA=-DHTRVT_EXP_OLDPACK LIB=... OBJDIR=...)
+  return (unsigned)from_f32<bf16_t>(lo).v | ((unsigned)from_f32<bf16_t>(hi).v << 16);
+#endif
   const f32x2_t f = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_raw_t));
 }
@@ -64,9 +67,18 @@ struct Vec16<bf16_t> {
     return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
   }
   __device__ __forceinline__ void set(int i, float v) {
+#ifdef HTRVT_EXP_OLDPACK
     unsigned b = from_f32<bf16_t>(v).v;
     unsigned& w = (&raw.x)[i >> 1];
     w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+#else
+    // element insertion into a first-class bfloat16 vector: set(0..7) in an unrolled loop becomes four
+    // v_cvt_pk_bf16_f32 (the mask-and-or form cost a conversion, a shift and a bit-field insert per element)
+    typedef __bf16 bf16x8_raw_t __attribute__((ext_vector_type(8)));
+    bf16x8_raw_t h = __builtin_bit_cast(bf16x8_raw_t, raw);
+    h[i] = (__bf16)v;
+    raw = __builtin_bit_cast(uint4, h);
+#endif
   }
 };
 

@@ -197,27 +197,45 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // ------------------------------------------------------------------ BN apply (+residual, +ReLU)
+// The per-channel coefficients sit in LDS and the channel index of a thread's vector advances by a constant per grid
+// stride (per element loads from global and a 64-bit modulo per vector were most of the kernel's instructions).
 template <typename T, int RES>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                       T* __restrict__ y, long long nvec, int C, int relu) {
   constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sco[];   // [2 or 4][C]: scale, shift [, rscale, rshift]
+  for (int k = threadIdx.x; k < C; k += NT) {
+    sco[k] = scale[k];
+    sco[C + k] = shift[k];
+    if constexpr (RES == 2) {
+      sco[2 * C + k] = rscale[k];
+      sco[3 * C + k] = rshift[k];
+    }
+  }
+  __syncthreads();
   const int cvec = C / CH;
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long long)gridDim.x * NT) {
-    const int c0 = (int)(i % cvec) * CH;
+  const long long stride = (long long)gridDim.x * NT;
+  const int step = (int)(stride % cvec);
+  long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  int cv = (int)(i % cvec);
+  for (; i < nvec; i += stride) {
+    const float* ca = sco + cv * CH;
     Vec16<T> v, r, o;
     v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[i];
     if constexpr (RES != 0) r.raw = reinterpret_cast<const decltype(r.raw)*>(res)[i];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      float a = fmaf(v.get(j), scale[c0 + j], shift[c0 + j]);
+      float a = fmaf(v.get(j), ca[j], ca[C + j]);
       if constexpr (RES == 1) a += r.get(j);
-      if constexpr (RES == 2) a += fmaf(r.get(j), rscale[c0 + j], rshift[c0 + j]);
+      if constexpr (RES == 2) a += fmaf(r.get(j), ca[2 * C + j], ca[3 * C + j]);
       if (relu) a = fmaxf(a, 0.f);
       o.set(j, a);
     }
     reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
+    cv += step;
+    if (cv >= cvec) cv -= cvec;
   }
 }
 
@@ -431,7 +449,7 @@ extern "C" int htrvt_bn_apply(const void* x, const float* scale, const float* sh
   dim3 grid(grid_for(nvec));
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BN_APPLY(T, R)                                                                                            \
-  hipLaunchKernelGGL((bn_apply_kernel<T, R>), grid, dim3(NT), 0, st, (const T*)x, scale, shift, (const T*)res, rscale, \
+  hipLaunchKernelGGL((bn_apply_kernel<T, R>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st, (const T*)x, scale, shift, (const T*)res, rscale, \
                      rshift, (T*)y, nvec, C, relu)
   if (dtype == HTRVT_BF16) {
     if (mode == 0) LAUNCH_BN_APPLY(bf16_t, 0);

@@ -19,16 +19,22 @@ def short(name):
     return n.split("(")[0][:90]
 
 
-def load(d):
-    """{kernel symbol: {counter: [value per dispatch]}} and {kernel: [duration ns per dispatch]}"""
+def load(d, by_grid=False):
+    """{kernel symbol: {counter: [value per dispatch]}} and {kernel: [duration ns per dispatch]}; by_grid: the key is
+    (symbol, workgroups of the launch) for the MFMA kernels"""
     vals, dur = defaultdict(lambda: defaultdict(list)), defaultdict(list)
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         per = defaultdict(dict)
         for r in csv.DictReader(open(f)):
-            per[(r["Dispatch_Id"], short(r["Kernel_Name"]))][r["Counter_Name"]] = float(r["Counter_Value"])
+            k = short(r["Kernel_Name"])
+            if by_grid:
+                k = (k, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+            per[(r["Dispatch_Id"], k)][r["Counter_Name"]] = float(r["Counter_Value"])
         for (_, k), cs in per.items():
             for c, v in cs.items():
                 vals[k][c].append(v)
+    if by_grid:
+        return vals, dur
     for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -60,6 +66,19 @@ def main():
                      wait_any / (wait_any + act) if wait_any + act else None))
         symbols[k] = {"launches_per_step": n / a.steps, "read_bytes_per_launch_mean": rd, "written_bytes_per_launch_mean": wb,
                       "traffic_bytes_per_launch_mean": rd + wb, "mfma_busy_fraction": util}
+    # per launch grid (= per launch shape) for the MFMA kernels
+    gfe, _ = load(os.path.join(a.src, "fetch"), by_grid=True)
+    gwr, _ = load(os.path.join(a.src, "write"), by_grid=True)
+    gmf, _ = load(os.path.join(a.src, "mfma"), by_grid=True)
+    grows = []
+    for key in gfe:
+        if not key[0].startswith(("gemm_", "attn_")):
+            continue
+        fs, ws = gfe[key].get("FETCH_SIZE", []), gwr.get(key, {}).get("WRITE_SIZE", [])
+        busy, gui = sum(gmf.get(key, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", [])), sum(gmf.get(key, {}).get("GRBM_GUI_ACTIVE", []))
+        grows.append((key[0], key[1], len(fs) / a.steps, 2.0 * 1024 * sum(fs) / max(1, len(fs)) / 1e6,
+                      1024.0 * sum(ws) / max(1, len(ws)) / 1e6, busy / (gui / 8.0 * 1024) if gui else None, gui / 8.0 / max(1, len(fs))))
+    grows.sort(key=lambda r: -(r[6] * r[2]))
     with open(a.dst + "_traffic.json", "w") as f:
         json.dump({"source": "tools/collect_pmc.sh (rocprofv3 --pmc, separate passes) over bench.py --steps 1 --warmup 1 "
                              "--no-overlap-wgrad; read bytes = 2 x FETCH_SIZE KiB x 1024, written = WRITE_SIZE KiB x 1024",
@@ -74,6 +93,11 @@ def main():
         for k, n, us, rd, wb, util, conf, wt in rows:
             f = lambda v, p=2: "-" if v is None else f"{v:.{p}f}"
             o.write(f"| `{k}` | {n:.1f} | {us:.1f} | {rd:.1f} | {wb:.1f} | {f(util)} | {f(conf, 3)} | {f(wt)} |\n")
+        o.write("\n## MFMA kernels per launch grid (one row = one launch shape; grid = workgroups = tiles_m x tiles_n [x split_k])\n\n")
+        o.write("| kernel | workgroups | launches/step | HBM read MB / launch | HBM written MB / launch | MFMA busy | kcycles / launch |\n")
+        o.write("|---|---:|---:|---:|---:|---:|---:|\n")
+        for k, grid, n, rd, wb, util, cyc in grows[:48]:
+            o.write(f"| `{k}` | {grid} | {n:.1f} | {rd:.1f} | {wb:.1f} | {'-' if util is None else f'{util:.2f}'} | {cyc / 1e3:.0f} |\n")
 
 
 if __name__ == "__main__":

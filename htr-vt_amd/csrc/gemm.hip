@@ -497,6 +497,8 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
                   "htrvt_gemm: parity-class dgrad extents inconsistent (expected M=%d K=%d)", d->nB * p.Hq * p.Wq,
                   p.ntapsel * d->Cpad);
   }
+  p.tappack = 0;
+  for (int t = 0; t < 12; ++t) p.tappack |= (unsigned long long)(p.tapsel[t] & 15) << (4 * t);
   const int zdim = p.split_k > 1 ? p.split_k : (d->batch > 1 ? d->batch : 1);
   HTRVT_REQUIRE((long long)p.tiles_m * p.tiles_n < (1ll << 31) && zdim < 65536, "htrvt_gemm: grid too large");
   hipStream_t st = (hipStream_t)stream;

@@ -47,6 +47,9 @@ struct KParams {
   int cls_h, cls_w, Hq, Wq, ntapsel;
   int wq_shift, hwq_shift;   // log2(Wq), log2(Hq*Wq) when both are powers of two, else -1 (epilogue row decode)
   unsigned char tapsel[12];
+  // the same list, 4 bits per entry, as ONE 64-bit scalar: indexing the kernarg array with the k-tile's tap position
+  // compiled to a global byte load + s_waitcnt vmcnt(0) inside the loader waves' issue path, twice per k-tile
+  unsigned long long tappack;
   // fused backward-of-ReLU and BatchNorm-backward column sums in the bf16 staged epilogue (conv dgrad outputs)
   const char* relu_src;
   const char* bnb_x[2];

@@ -184,7 +184,7 @@ struct DmaLoader {
     int tap_dy = 0, tap_dx = 0, cbase = k0;
     if constexpr (ROLE == 1 || ROLE == 2 || KMAP) {
       const int ti = k0 / p.Cpad;
-      const int tap = p.tapsel[ti];
+      const int tap = (int)((p.tappack >> (4 * ti)) & 15ull);   // = p.tapsel[ti], without the memory round trip
       cbase = k0 - ti * p.Cpad;
       tap_dy = tap / p.kw;
       tap_dx = tap - tap_dy * p.kw;

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
     ap.add_argument("--sam", action="store_true", help="the reference's full iteration (train.py:119-128): SAM(AdamW) = two "
                     "fwd+bwd passes + climb/restore + AdamW + ModelEma update; images/s counts each image once")
+    ap.add_argument("--rehearse-collectives", action="store_true", help="N = 1 under a launcher: run the RCCL gradient "
+                    "all-reduces anyway (exercises the N > 1 code path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the short float32 parity-path timing beside the bf16 line")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
@@ -150,7 +152,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or "RANK" in os.environ      # under torch.distributed.run the RCCL path runs even at N=1
+    # one rank needs no collective: under a launcher at N = 1 the process group is still created (the launcher's
+    # contract), but gradients are not "all-reduced" with themselves (RCCL's one-rank all-reduce of the 214 MB buffer
+    # costs 2.4 ms per step) unless --rehearse-collectives asks for the full N > 1 code path on one GPU
+    use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -185,7 +190,8 @@ def main():
             return nll
     else:
         model.train()
-        tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world, use_collectives=use_dist)
+        tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world,
+                     use_collectives=use_dist and (world > 1 or args.rehearse_collectives))
         tr.engine.fuse_bn_backward = not args.no_fuse_bn
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
         tr.engine.deterministic = tr.engine.deterministic or args.deterministic

@@ -160,7 +160,9 @@ int htrvt_seq_whiten_fwd(const void* x, float* y, float* stats, int B, int NC, f
 /* logits [B][T][C] float32; targets concatenated int32; tgt_len/tgt_off [B] int32.
  * nll[b] (0 if infeasible, zero_infinity); grad[b][t][c] = grad_scale * d(mean_b nll)/dlogits (NULL to skip;
  * grad_scale = 1/world_size folds the data-parallel gradient average into the loss).
- * workspace: float32, htrvt_ctc_workspace_floats(B,T,Smax) elements. */
+ * workspace: float32, htrvt_ctc_workspace_floats(B, T, max_target_len) elements (alpha, beta, frame log-sum-exp).
+ * Targets of up to 127 labels: frame log-sum-exp, the alpha and beta recursions side by side (one wave each per
+ * sample), then the gradient of all (b, t) rows in parallel; longer targets: one workgroup per sample. */
 size_t htrvt_ctc_workspace_floats(int B, int T, int max_target_len);
 int htrvt_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_len, const int32_t* tgt_off,
                    float* nll, float* grad, float* workspace, int B, int T, int C, int max_target_len,

@@ -150,6 +150,23 @@ def test_ctc_kernel_known_answers(golden_dir, name):
         assert nll[b].item() == 0.0 and not grad[b].any().item()
 
 
+def test_ctc_long_targets_take_the_workgroup_per_sample_kernel():
+    """more than 127 labels: S = 2L+1 > 256 states do not fit one wave's registers -> ctc_kernel (one workgroup per sample;
+    its S > 256 and S <= 256 branches both run here); same oracle, same tolerances as the known-answer cases"""
+    import htrvt_amd
+    rng = np.random.default_rng(5)
+    B, T, C = 3, 384, 40
+    lengths = np.array([150, 100, 128], dtype=np.int32)
+    targets = rng.integers(1, C, size=int(lengths.sum())).astype(np.int32)
+    logits = rng.standard_normal((B, T, C)).astype(np.float32)
+    nll, grad = htrvt_amd.ctc_forward_backward(torch.from_numpy(logits).cuda(), targets, lengths)
+    ref64, _, grad64 = O.ctc_loss(logits, targets, lengths)
+    assert np.abs(nll.cpu().numpy() - ref64).max() <= 1e-5 * np.abs(ref64).max()
+    assert np.abs(grad.cpu().numpy() - grad64).max() < 4e-3 * np.abs(grad64).max()
+    nll2, none = htrvt_amd.ctc_forward_backward(torch.from_numpy(logits).cuda(), targets, lengths, want_grad=False)
+    assert none is None and torch.equal(nll, nll2)
+
+
 def test_create_model_surface_and_bf16_training_step():
     """reference API: create_model(nb_cls, img_size) / forward(image, ratio, span, use_masking=True)"""
     import htrvt_amd

@@ -515,6 +515,78 @@ __global__ __launch_bounds__(NT) void pool_tokens_bwd_kernel(const T* __restrict
   }
 }
 
+// H == 2 (every 64-pixel-high line image: one pooled row): one thread per (b, column, channel vector) loads the 2 x 5
+// inputs that the three windows containing its column read, finds the three arg-maxes in registers and writes both rows'
+// gradients -- 13 loads per two outputs instead of 42 (the general kernel re-derives every window per input element).
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_tokens_bwd_h2_kernel(const T* __restrict__ dtok, const T* __restrict__ x,
+                                                                const float* __restrict__ keep, T* __restrict__ dx, int B,
+                                                                int W, int D) {
+  constexpr int CH = Vec16<T>::N;
+  using Raw = decltype(Vec16<T>().raw);
+  const int cvec = D / CH;
+  const long long total = (long long)B * W * cvec;
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i >= total) return;
+  const int cv = (int)(i % cvec);
+  const long long t = i / cvec;
+  const int wi = (int)(t % W), b = (int)(t / W);
+  const Raw* xr = reinterpret_cast<const Raw*>(x) + (long long)b * 2 * W * cvec + cv;
+  const Raw* dr = reinterpret_cast<const Raw*>(dtok) + (long long)b * W * cvec + cv;
+  // columns wi-2 .. wi+2 of both rows and the three token gradients, all in flight together (clamped addresses)
+  Vec16<T> v[2][5], g[3];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int w2 = min(max(wi - 2 + c, 0), W - 1);
+    v[0][c].raw = xr[(long long)w2 * cvec];
+    v[1][c].raw = xr[(long long)(W + w2) * cvec];
+  }
+  bool live[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {   // window centred on column wo = wi - 1 + k
+    const int wo = wi - 1 + k, woc = min(max(wo, 0), W - 1);
+    live[k] = wo >= 0 && wo < W && (keep == nullptr || keep[woc] != 0.f);
+    g[k].raw = dr[(long long)woc * cvec];
+  }
+  float acc[2][CH];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[r][j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // first maximum of the window in (row, column) scan order; its columns are v[.][k .. k+2], this thread's column is
+    // window column 2 - k
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float m = -INFINITY;
+      int am = -1;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int w2 = wi - 2 + k + c;
+          const float a = (w2 >= 0 && w2 < W) ? v[r][k + c].get(j) : -INFINITY;
+          if (a > m) {
+            m = a;
+            am = r * 3 + c;
+          }
+        }
+      const float gv = live[k] ? g[k].get(j) : 0.f;
+      if (am == 2 - k) acc[0][j] += gv;
+      if (am == 3 + 2 - k) acc[1][j] += gv;
+    }
+  }
+  Raw* dxr = reinterpret_cast<Raw*>(dx) + ((long long)b * 2 * W + wi) * cvec + cv;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o.set(j, acc[r][j]);
+    dxr[(long long)r * W * cvec] = o.raw;
+  }
+}
+
 // ------------------------------------------------------------------ conv1 weight gradient (Cin = 1)
 // partial[blk][C*9] = sum over the block's output rows of dY[pix][c] * whitened tap
 template <typename T>
@@ -842,6 +914,12 @@ extern "C" int htrvt_pool_tokens_bwd(const void* dtok, const void* x, const floa
   const int Ho = (H - 1) / 2 + 1;
   HTRVT_REQUIRE(D % ch == 0 && N % Ho == 0, "htrvt_pool_tokens_bwd: bad shape");
   const int W = N / Ho;
+  if (H == 2) {
+    const long long threads = (long long)B * W * (D / ch);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pool_tokens_bwd_h2_kernel<T>, dim3((unsigned)((threads + NT - 1) / NT)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const T*)dtok, (const T*)x, keep, (T*)dx, B, W, D));
+    return check_launch("pool_tokens_bwd");
+  }
   const long long total = (long long)B * H * W * (D / ch);
   dim3 grid(grid_for(total));
   DISPATCH_T(dtype, hipLaunchKernelGGL(pool_tokens_bwd_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, (const T*)dtok,

@@ -50,3 +50,43 @@ def test_colsum(rows, cols, ld, dtype):
     colsum(x, rows, cols, ld, out2, dti=dt(dtype), keep=keep, keep_mod=N)
     sel = keep[torch.arange(rows, device="cuda") % N] == 0
     assert torch.equal(out2, x[sel][:, :cols].float().sum(0))
+
+
+@pytest.mark.parametrize("H,W,D", [(2, 256, 768), (2, 37, 64), (4, 48, 64), (5, 16, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pool_tokens_and_its_backward_match_max_pool2d(H, W, D, dtype):
+    """final max_pool2d(3, stride (2,1), pad 1) + span mask + pos-embed (HTR_VT.py:226-236) and its backward, through
+    the C ABI, against torch's max_pool2d autograd on the CPU; H = 2 takes the one-pooled-row kernel, H > 2 the general
+    one."""
+    lib, check, ptr, stream = _lib()
+    from htrvt_amd.ops import dt
+    B = 3
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    Ho = (H - 1) // 2 + 1
+    N = Ho * W
+    # every 3x3 window sees the nine cells (h % 3, w % 3) once: a per-(image, channel) random permutation of 0..8 laid out
+    # periodically has a unique maximum in every window (clipped ones too) and is exact in bfloat16
+    perm = torch.stack([torch.randperm(9, generator=g) for _ in range(B * D)]).view(B, D, 9).float()
+    cell = (torch.arange(H).view(H, 1) % 3) * 3 + (torch.arange(W).view(1, W) % 3)
+    x = perm[:, :, cell.view(-1)].view(B, D, H, W)
+    keep = (torch.rand(N, generator=g) > 0.3).float()
+    dtok = torch.randint(-8, 9, (B, N, D), generator=g).float()
+    xr = x.clone().requires_grad_(True)
+    pooled = torch.nn.functional.max_pool2d(xr, kernel_size=3, stride=(2, 1), padding=1)   # [B, D, Ho, W]
+    tok_ref = pooled.permute(0, 2, 3, 1).reshape(B, N, D)
+    (tok_ref * keep.view(1, N, 1) * dtok).sum().backward()
+    dx_ref = xr.grad.permute(0, 2, 3, 1).contiguous()       # NHWC, as the kernels see it
+
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    keep_d, dtok_d = keep.cuda(), dtok.to(dtype).cuda()     # named: a temporary would be freed (and reused) before the launch
+    mask_token = torch.full((D,), -7.0).cuda()
+    pos = torch.zeros(N, D).cuda()
+    tok = torch.empty(B, N, D, dtype=dtype, device="cuda")
+    check(lib.htrvt_pool_tokens(ptr(x_d), ptr(keep_d), ptr(mask_token), ptr(pos), ptr(tok), B, H, N, D, dt(dtype), stream()),
+          "pool_tokens")
+    want = torch.where(keep.view(1, N, 1) != 0, tok_ref.detach(), torch.tensor(-7.0))
+    assert torch.equal(tok.float().cpu(), want)
+    dx = torch.empty(B, H, W, D, dtype=dtype, device="cuda")
+    check(lib.htrvt_pool_tokens_bwd(ptr(dtok_d), ptr(x_d), ptr(keep_d), ptr(dx), B, H, N, D, dt(dtype), stream()),
+          "pool_tokens_bwd")
+    assert torch.equal(dx.float().cpu(), dx_ref)

@@ -98,7 +98,8 @@ def test_adamw_kernel_matches_torch_optim():
         v_prev = st["exp_avg_sq"].clone() if "exp_avg_sq" in st else torch.zeros(n)
         p_ref.grad = g.clone()
         opt.step()
-        check(lib.htrvt_adamw(ptr(p), ptr(g.cuda()), ptr(m), ptr(v), n, 1e-3, 0.9, 0.99, 1e-8, 0.5, step, stream()), "adamw")
+        g_d = g.cuda()   # named: the launch must not read a tensor that has already been freed
+        check(lib.htrvt_adamw(ptr(p), ptr(g_d), ptr(m), ptr(v), n, 1e-3, 0.9, 0.99, 1e-8, 0.5, step, stream()), "adamw")
         st = opt.state[p_ref]
         # 4 ulps of the LARGEST quantity entering each update (m + w (g - m) cancels when g ~ -m: the error is an ulp of
         # the operands, not of the small result; the parameter update is of size lr)

@@ -89,8 +89,9 @@ __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
 // NWM = number of waves stacked along M in the workgroup (for the BN column-sum reduction through LDS).
 // EXTRAS: compile the per-column scale and the trailing ReLU (eval-mode BatchNorm folded into a convolution); the
 // 256-column LDS-DMA kernels (float32 split-K weight gradients) leave them out: they have no SGPRs to spare
-template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS, bool EXTRAS = true>
-__device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const KParams& p, char* Cb, long long coff, int mrow0,
+// P: KParams, or KParams in the constant address space (the LDS-DMA kernels read it straight from the kernarg segment)
+template <typename T, int TM, int TN, int NWM, int BN, int NTHREADS, bool EXTRAS = true, class P = KParams>
+__device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const P& p, char* Cb, long long coff, int mrow0,
                                               int ncol0, int wm, int n0, int tile_m, int lane, char* smem,
                                               bool active = true) {
   // active == false: a wave that holds no accumulators (dedicated loader wave); it only joins the barriers

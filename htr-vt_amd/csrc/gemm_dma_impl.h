@@ -85,7 +85,8 @@ struct Geo {
   }
 };
 
-__device__ __forceinline__ void pix_decode(const KParams& p, int m, int& b, int& ho, int& wo) {
+template <class P>
+__device__ __forceinline__ void pix_decode(const P& p, int m, int& b, int& ho, int& wo) {
   if (p.howo_shift >= 0) {
     b = m >> p.howo_shift;
     const int r = m & ((1 << p.howo_shift) - 1);
@@ -115,7 +116,8 @@ struct DmaLoader {
   unsigned tapoff[NP];
   int cur_ti;
 
-  __device__ __forceinline__ void init(const KParams& p, const char* base, long long ld, int row0, int rows_total, int wave,
+  template <class P>
+  __device__ __forceinline__ void init(const P& p, const char* base, long long ld, int row0, int rows_total, int wave,
                                        int lane) {
     const unsigned long long ba = (unsigned long long)base;  // raw buffer, stride 0, 2 GiB of records
     rsrc = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
@@ -179,8 +181,8 @@ struct DmaLoader {
   }
 
   // kmap: plain K-major operand (the packed conv weights) whose k runs over a SELECTED tap list
-  template <bool KMAP = false>
-  __device__ __forceinline__ void issue(const KParams& p, unsigned lds_tile, int k0, int kend, int wave) {
+  template <bool KMAP = false, class P = KParams>
+  __device__ __forceinline__ void issue(const P& p, unsigned lds_tile, int k0, int kend, int wave) {
     int tap_dy = 0, tap_dx = 0, cbase = k0;
     if constexpr (ROLE == 1 || ROLE == 2 || KMAP) {
       const int ti = k0 / p.Cpad;
@@ -290,8 +292,8 @@ __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w &
 
 // DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
 // CSTATS: compile the per-column sum / sum-of-squares path (conv-forward kernels only: BatchNorm batch statistics)
-template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS>   // CSTATS (conv forward) also enables colscale / ReLU-last
-__device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KParams& p, long long coff, int m0, int n0,
+template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS, class P>   // CSTATS (conv forward) also enables colscale / ReLU-last
+__device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P& p, long long coff, int m0, int n0,
                                                 int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
   constexpr int CST = Stg<BM>::CST;
   constexpr int NWAVES = NW_TOTAL, NTH = NW_TOTAL * 64, NWM = BM / 64;
@@ -638,8 +640,8 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const KP
 // landed, so two k-tiles are in flight while one is multiplied.  With two stages the next DMA cannot start before
 // the barrier that follows the previous one's arrival, and the loop is bound by one DMA round trip per k-tile
 // (measured with the MFMAs removed: 2 400-3 300 cycles per k-tile against 1 900 for the MFMA side alone).
-template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>
-__global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KParams p) {
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE, class P>
+__device__ __forceinline__ void gemm_dma_body(const P& p, const int block_x) {
   using T = bf16_t;
   constexpr int NWC = BM / 32;                 // consumer (MFMA) waves
   constexpr int NWL = SPEC ? 4 : NWC;          // waves that issue DMA
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
 
   HTRVT_STAMP(0);
   const int ntiles = p.tiles_m * p.tiles_n;
-  int id = blockIdx.x;
+  int id = block_x;
   int z = blockIdx.z;
   if (p.split_k > 1 && (p.split_k & 7) == 0) {
     // Split-K by a multiple of 8 (weight gradients): the output tiles that share one K range read the SAME operand rows (for a conv, the
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
     // dealt round-robin over the 8 XCDs: linear block L -> chunk c of 8*ntiles blocks, XCD slot x = L % 8 owns K range
     // 8c + x and runs its ntiles tiles back to back.  (Measured before this mapping: the layer-1 conv wgrad fetched
     // 5.7 GB per launch against 0.8 GB of operands -- every tile streamed the pixels from HBM on a different XCD.)
-    const int L = blockIdx.x;
+    const int L = block_x;
     const int chunk = L / (8 * ntiles), r = L - chunk * 8 * ntiles;
     z = chunk * 8 + (r & 7);
     id = r >> 3;
@@ -809,6 +811,16 @@ __global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KPa
     htrvt_dbg[blockIdx.x * 16 + 8] = hw;
   }
 #endif
+}
+
+template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>
+__global__ __launch_bounds__(BM * 2 + SPEC * 256) void gemm_dma_kernel(const KParams p) {
+  // the parameters are read where they lie, in the kernarg segment (p is the only argument: offset 0), through a
+  // constant-address-space reference: scalar loads, never a private copy of the struct
+  typedef const __attribute__((address_space(4))) KParams KP;
+  (void)p;
+  KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+  gemm_dma_body<BM, BN, AL, BL, GATHER, SPEC, NSTAGE>(*kp, (int)blockIdx.x);
 }
 
 template <int BM, int BN, int AL, int BL, int GATHER, int SPEC, int NSTAGE = 2>

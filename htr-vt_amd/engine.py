@@ -230,6 +230,10 @@ class Engine:
         with torch.cuda.stream(self._side):
             return fn()
 
+    def _wgrad_stream(self):
+        """the stream weight gradients are running on, None when they share the main stream"""
+        return self._side if (self._side is not None and self._side_active) else None
+
     def _join_side(self):
         if self._side is not None and self._side_active:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -659,8 +663,7 @@ class Engine:
                              G[p + ".norm1.bias"])
 
         if after_encoder is not None:   # every blocks.*, norm, head gradient is enqueued: DP bucket can go
-            self._join_side()
-            after_encoder()
+            after_encoder(self._wgrad_stream())      # (the collective waits for the weight-gradient stream, not this one)
 
         # token assembly
         keep = sv["keep"]
@@ -695,8 +698,7 @@ class Engine:
             p = blk["p"]
             C = blk["cb"].shape[-1]
             if bi == len(blocks) - 3 and after_layer3 is not None:   # both layer-3 blocks (78 % of the stem's weights) are done
-                self._join_side()
-                after_layer3()
+                after_layer3(self._wgrad_stream())
             if parts is None:   # dout is an unmasked gradient: classic path (mask + sums in one reduction pass)
                 dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3],
                                            want_g=True)

@@ -65,7 +65,14 @@ class FlatParams:
             if p.requires_grad and p.data.untyped_storage().data_ptr() != base:
                 raise RuntimeError(f"parameter {n} was re-bound outside the flat buffer; rebuild the Trainer")
 
-    def reduce_encoder_bucket(self):
+    def _behind(self, producer):
+        """the collective stream waits for everything enqueued so far on the current stream and on `producer` (the
+        engine's weight-gradient stream): the bucket is complete then, and the main stream itself never stalls"""
+        self.side.wait_stream(torch.cuda.current_stream())
+        if producer is not None:
+            self.side.wait_stream(producer)
+
+    def reduce_encoder_bucket(self, producer=None):
         """all-reduce(SUM) of the blocks.*/norm/head gradients; on CUDA on the side stream, overlapping
         whatever the current stream enqueues next (the stem backward)."""
         if not self.coll:
@@ -73,11 +80,11 @@ class FlatParams:
         if self.side is None:
             dist.all_reduce(self.flat_g[self.enc_start:])
             return
-        self.side.wait_stream(torch.cuda.current_stream())
+        self._behind(producer)
         with torch.cuda.stream(self.side):
             dist.all_reduce(self.flat_g[self.enc_start:])
 
-    def reduce_layer3_bucket(self):
+    def reduce_layer3_bucket(self, producer=None):
         """all-reduce(SUM) of the patch_embed.layer3.* gradients, complete after the first two stem blocks of the
         backward; on CUDA on the side stream behind the encoder bucket, under the layer-2/1 backward."""
         if not self.coll or self.l3_start == self.enc_start:
@@ -85,7 +92,7 @@ class FlatParams:
         if self.side is None:
             dist.all_reduce(self.flat_g[self.l3_start:self.enc_start])
             return
-        self.side.wait_stream(torch.cuda.current_stream())
+        self._behind(producer)
         with torch.cuda.stream(self.side):
             dist.all_reduce(self.flat_g[self.l3_start:self.enc_start])
 

@@ -18,12 +18,20 @@ def _prep_targets(targets, target_lengths, device):
     tg = torch.as_tensor(targets, dtype=torch.int32)
     if tg.numel() == 0:
         tg = torch.zeros(1, dtype=torch.int32)
-    return tg.to(device), tl.to(device), off.to(device), maxlen
+    return _upload(tg, device), _upload(tl, device), _upload(off, device), maxlen
+
+
+def _upload(t, device):
+    """host -> device through pinned memory, stream-ordered: a copy from pageable memory would block the host until
+    everything already enqueued (the previous training step) has finished, once per step"""
+    if t.is_cuda or torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
 def stage_targets(targets, target_lengths, device):
-    """upload the label arrays (three small host->device copies).  Call it BEFORE enqueueing the forward: a copy from
-    pageable memory waits for everything already on the stream, i.e. it would stall the host for a whole forward."""
+    """upload the label arrays (three small host->device copies through pinned memory: the host does not wait for the
+    device)."""
     return _prep_targets(targets, target_lengths, device)
 
 

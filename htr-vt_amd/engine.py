@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -423,7 +425,9 @@ class Engine:
         C1 = s.D // 4
         keep = None
         if keep_mask is not None:   # uploaded before anything is enqueued: a pageable host->device copy waits for the stream
-            keep = keep_mask.to(device=self.dev, dtype=torch.float32).contiguous()
+            keep = keep_mask.to(dtype=torch.float32).contiguous()
+            if not keep.is_cuda:    # through pinned memory: a pageable copy would make the host wait for the previous step
+                keep = keep.pin_memory().to(self.dev, non_blocking=True)
 
         prefetched = False
         if self.prefetch_packs and self.dtype == torch.bfloat16:

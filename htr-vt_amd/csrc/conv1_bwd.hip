@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_reduce_kernel(const float* __re
     out[(long long)blockIdx.y * ld + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(1024) void conv1_bwd_finalize_kernel(const float* __restrict__ part, int S, int ld, int C,
+__global__ __launch_bounds__(512) void conv1_bwd_finalize_kernel(const float* __restrict__ part, int S, int ld, int C,
                                                                  double count, const float* __restrict__ w,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ mean,
@@ -259,7 +259,7 @@ extern "C" int htrvt_conv1_bwd(const void* img, const float* stats, const void* 
   float* red = partial + (long long)nrows * ld;
   conv1_bwd_reduce_kernel<<<dim3((ld + 63) / 64, S_ROWS), 256, 0, st>>>(partial, red, nrows, ld);
   HTRVT_REQUIRE((size_t)ld * sizeof(double) <= 64 * 1024, "conv1_bwd: C=%d too wide for the finalize kernel's LDS", C);
-  conv1_bwd_finalize_kernel<<<1, 1024, (size_t)ld * sizeof(double), st>>>(red, S_ROWS, ld, C, (double)B * Hc * W, w, gamma, mean, rstd, dw,
+  conv1_bwd_finalize_kernel<<<1, 512, (size_t)ld * sizeof(double), st>>>(red, S_ROWS, ld, C, (double)B * Hc * W, w, gamma, mean, rstd, dw,
                                                                         dgamma, dbeta);
   return check_launch("conv1_bwd");
 }

@@ -19,8 +19,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# Before the HIP runtime starts: the step uses four streams of its own (main, weight gradients, weight packs, gradient
+# collectives) and RCCL adds more; with HIP's default of 4 hardware queues per process the main and the weight-gradient
+# stream of a data-parallel run landed on the SAME queue and ran one after the other (43.8 ms per step instead of 41.0).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

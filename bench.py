@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-parity-path", action="store_true", help="skip the short float32 parity-path timing beside the bf16 line")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
+    ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: conv1 tensor materialised (conv1_fwd + bn_relu_maxpool) "
+                    "instead of the one-pass stem forward")
     ap.add_argument("--deterministic", action="store_true", help="A/B: split-K weight gradients through ordered slabs instead "
                     "of float atomics also on the bf16 path (the float32 path always does)")
     ap.add_argument("--parallel-classes", action="store_true", help="A/B: parity-class dgrad launches of a strided conv on separate streams")
@@ -187,6 +189,7 @@ def main():
     if args.forward_only:
         model.eval()
         eng = model._engine(dev)
+        eng.fuse_stem_forward = not args.no_fuse_stem
         P = dict(model.state_dict(keep_vars=True))
 
         def one_step():
@@ -199,6 +202,7 @@ def main():
                      use_collectives=use_dist and (world > 1 or args.rehearse_collectives))
         tr.engine.fuse_bn_backward = not args.no_fuse_bn
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
+        tr.engine.fuse_stem_forward = not args.no_fuse_stem
         tr.engine.deterministic = tr.engine.deterministic or args.deterministic
         tr.engine.fused_attention = not args.no_fused_attention
         tr.engine.parallel_classes = args.parallel_classes

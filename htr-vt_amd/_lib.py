@@ -47,6 +47,9 @@ PROTOTYPES = {
     "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
     "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "htrvt_stem_stats_rows": (i32, [i32, i32]),
+    "htrvt_stem_stats": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "htrvt_stem_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, vp]),
     "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -166,6 +166,263 @@ __global__ __launch_bounds__(NT) void conv1_fwd_kernel(const void* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ fused stem forward
+// conv1 (ONE input channel) -> train-mode BatchNorm -> ReLU -> max_pool2d(3, stride (2,1), pad 1) without ever writing
+// the conv1 tensor (1.6 GB at B=128, 64x1024, C1=192 in bf16; it was written once and read once).
+//
+// Batch statistics without the tensor: with xw_t(pos) the whitened image tap t at conv position pos,
+//   y_c(pos) = sum_t W[c][t] xw_t(pos)   =>   sum_pos y_c   = sum_t W[c][t] X[t]
+//                                              sum_pos y_c^2 = sum_{t,u} W[c][t] W[c][u] R[t][u]
+// where X[t] = sum_pos xw_t and R[t][u] = sum_pos xw_t xw_u are 9 + 45 sums over the IMAGE (stem_moments_kernel: one
+// pass over 8-34 MB), combined per channel in double precision (stem_stats_kernel) into the (sum, sum of squares) row
+// that htrvt_bn_finalize takes.  conv1_bwd.hip uses the same identities for the backward.
+constexpr int NMOM = 54;   // 9 tap sums + 45 upper-triangle tap products
+
+// one block per conv row (b, ho): partial[block][64] (54 used)
+__global__ __launch_bounds__(NT) void stem_moments_kernel(const void* __restrict__ img, const float* __restrict__ stats,
+                                                          float* __restrict__ partial, int H, int W, int u8) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2]
+  __shared__ float red[NT / 64][NMOM];
+  const int Ho = H / 2;
+  const int b = blockIdx.x / Ho, ho = blockIdx.x - b * Ho;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const int WP = W + 2;
+  for (int i = threadIdx.x; i < 3 * WP; i += NT) {
+    const int r = i / WP, c = i - r * WP;
+    const int hi = 2 * ho - 1 + r, wi = c - 1;
+    float v = 0.f;
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
+    rows[i] = v;
+  }
+  __syncthreads();
+  float acc[NMOM];
+#pragma unroll
+  for (int k = 0; k < NMOM; ++k) acc[k] = 0.f;
+  for (int px = threadIdx.x; px < W; px += NT) {
+    float x[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[r * 3 + c] = rows[r * WP + px + c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[t] += x[t];
+#pragma unroll
+      for (int u = t; u < 9; ++u) acc[9 + t * 9 - t * (t - 1) / 2 + (u - t)] += x[t] * x[u];   // upper triangle, row-major
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NMOM; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = 0.f;
+    if (threadIdx.x < NMOM) {
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) v += red[w][threadIdx.x];
+    }
+    partial[(long long)blockIdx.x * 64 + threadIdx.x] = v;
+  }
+}
+
+// one block of 512 threads: 64 columns x 8 row lanes sum the partial rows in double, then thread c < C forms the
+// channel's (sum y, sum y^2) -> colstats[0][c], colstats[1][c]
+constexpr int SS_RL = 8;
+__global__ __launch_bounds__(64 * SS_RL) void stem_stats_kernel(const float* __restrict__ partial, int nrows,
+                                                                const float* __restrict__ w, float* __restrict__ colstats, int C) {
+  __shared__ double red[SS_RL][64];
+  __shared__ double X[9], R[9][9];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  double a = 0.0;
+  int r = rl;
+  for (; r + 7 * SS_RL < nrows; r += 8 * SS_RL) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(r + SS_RL * u) * 64 + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; r < nrows; r += SS_RL) a += partial[(long long)r * 64 + col];
+  red[rl][col] = a;
+  __syncthreads();
+  if (threadIdx.x < NMOM) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < SS_RL; ++k) t += red[k][threadIdx.x];
+    if (threadIdx.x < 9) {
+      X[threadIdx.x] = t;
+    } else {
+      int k = threadIdx.x - 9, i = 0;
+      while (k >= 9 - i) {
+        k -= 9 - i;
+        ++i;
+      }
+      R[i][i + k] = t;
+      R[i + k][i] = t;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 64 * SS_RL) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < 9; ++t) {
+      const double wt = w[c * 9 + t];
+      s1 += wt * X[t];
+      double rr = 0.0;
+      for (int u = 0; u < 9; ++u) rr += (double)w[c * 9 + u] * R[t][u];
+      s2 += wt * rr;
+    }
+    colstats[c] = (float)s1;
+    colstats[C + c] = (float)s2;
+  }
+}
+
+// One block per pooled row (b, ph): the 7 whitened image rows that its 3 conv rows touch live in LDS.  A thread owns CH
+// consecutive channels (weights, scale, shift in registers) and a contiguous run of columns: per new column it computes
+// the 3 conv rows (same FMA order as conv1_fwd_kernel), BatchNorm + ReLU, the column's maximum with its row, and
+// combines it with the two previous columns into the pooled output -- first maximum in (row, column) scan order, as
+// ATen's max_pool2d and bn_relu_maxpool_kernel.  idx = 3 * row + column of the arg-max, 15 where the ReLU is closed.
+template <typename T>
+__global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restrict__ img, const float* __restrict__ stats,
+                                                            const float* __restrict__ w, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ y,
+                                                            unsigned char* __restrict__ idx, int H, int W, int C, int nthr,
+                                                            int u8) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rows = reinterpret_cast<float*>(smem_raw);  // [7][W+2]
+  const int Hc = H / 2, Hp = (Hc - 1) / 2 + 1, WP = W + 2;
+  const int b = blockIdx.x / Hp, ph = blockIdx.x - b * Hp;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  for (int i = threadIdx.x; i < 7 * WP; i += NT) {
+    const int r = i / WP, c = i - r * WP;
+    const int hi = 4 * ph - 3 + r, wi = c - 1;
+    float v = 0.f;
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
+    rows[i] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= nthr) return;
+  const int lanes_per_pix = C / CH, ppb = nthr / lanes_per_pix;
+  const int cg = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
+  const int seg = (W + ppb - 1) / ppb, w0 = pl * seg, w1 = min(W, w0 + seg);
+  if (w0 >= w1) return;
+  // channel pairs as 2-vectors: the 27 FMAs of a (column, channel) become v_pk_fma_f32 over two channels (same
+  // per-channel operation order as conv1_fwd_kernel, so the float32 values are identical)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 wr[CH / 2][9], sc[CH / 2], sf[CH / 2];
+#pragma unroll
+  for (int j = 0; j < CH / 2; ++j) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = f32x2{w[(cg * CH + 2 * j) * 9 + t], w[(cg * CH + 2 * j + 1) * 9 + t]};
+    sc[j] = f32x2{scale[cg * CH + 2 * j], scale[cg * CH + 2 * j + 1]};
+    sf[j] = f32x2{shift[cg * CH + 2 * j], shift[cg * CH + 2 * j + 1]};
+  }
+  // conv row k of this pooled row = conv row 2 ph - 1 + k; rows outside the conv output are pooling padding (-inf)
+  bool rowok[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rowok[k] = (2 * ph - 1 + k) >= 0 && (2 * ph - 1 + k) < Hc;
+  // the two previous columns' (maximum, its row)
+  float pv[2][CH];
+  int pr[2][CH];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      pv[q][j] = -INFINITY;
+      pr[q][j] = 0;
+    }
+  T* yrow = y + ((long long)blockIdx.x * W) * C + cg * CH;
+  unsigned char* irow = idx ? idx + ((long long)blockIdx.x * W) * C + cg * CH : nullptr;
+  for (int c = w0 - 1; c <= w1; ++c) {   // conv column c; the output of column c - 1 is complete once c is known
+    float cv[CH];
+    int cr[CH];
+    if (c >= 0 && c < W) {
+      float xin[7][3];
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[r][d] = rows[r * WP + c + d];
+#pragma unroll
+      for (int j = 0; j < CH / 2; ++j) {
+        float m[2] = {-INFINITY, -INFINITY};
+        int mr[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (!rowok[k]) continue;   // block-uniform: pooling padding above the first / below the last conv row
+          f32x2 a = {0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float xv = xin[2 * k + t / 3][t % 3];
+            a = __builtin_elementwise_fma(wr[j][t], f32x2{xv, xv}, a);
+          }
+          const f32x2 bn = __builtin_elementwise_fma(a, sc[j], sf[j]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float v = fmaxf(bn[e], 0.f);
+            const bool take = v > m[e];
+            m[e] = take ? v : m[e];
+            mr[e] = take ? k : mr[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          cv[2 * j + e] = m[e];
+          cr[2 * j + e] = mr[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        cv[j] = -INFINITY;
+        cr[j] = 0;
+      }
+    }
+    const int wo = c - 1;
+    if (wo >= w0 && wo < w1) {   // window columns wo-1, wo, wo+1 = pv[0], pv[1], cv
+      Vec16<T> o;
+      unsigned am[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float m = pv[0][j];
+        int r = pr[0][j], col = 0;
+        // a later column wins only with a larger value, or an equal one in an EARLIER row (row-major scan order)
+        bool t1 = pv[1][j] > m || (pv[1][j] == m && pr[1][j] < r);
+        m = t1 ? pv[1][j] : m;
+        r = t1 ? pr[1][j] : r;
+        col = t1 ? 1 : col;
+        bool t2 = cv[j] > m || (cv[j] == m && cr[j] < r);
+        m = t2 ? cv[j] : m;
+        r = t2 ? cr[j] : r;
+        col = t2 ? 2 : col;
+        o.set(j, m);
+        am[j] = !(m > 0.f) ? 15u : (unsigned)(3 * r + col);
+      }
+      *reinterpret_cast<decltype(o.raw)*>(yrow + (long long)wo * C) = o.raw;
+      if (irow != nullptr) {
+        unsigned char* dst = irow + (long long)wo * C;
+        const unsigned q0 = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+        if constexpr (CH == 8) {
+          const unsigned q1 = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(q0, q1);
+        } else {
+          *reinterpret_cast<unsigned*>(dst) = q0;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      pv[0][j] = pv[1][j];
+      pr[0][j] = pr[1][j];
+      pv[1][j] = cv[j];
+      pr[1][j] = cr[j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ BN coefficients
 // stage 1: rows -> S partial rows;  grid (ceil(C/64), S), block 256 = 64 channels x 4 row lanes
 __global__ __launch_bounds__(NT) void bn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows,
@@ -468,6 +725,44 @@ extern "C" int htrvt_conv1_fwd(const void* img, const float* stats, const float*
     hipLaunchKernelGGL(conv1_fwd_kernel<float>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, (float*)out,
                        colstats, H, W, C, nthr, img_u8);
   return check_launch("conv1_fwd");
+}
+
+extern "C" int htrvt_stem_stats_rows(int B, int H) { return B * (H / 2); }
+
+// (sum, sum of squares) of the conv1 output per channel, from the image alone -> colstats [2][C] (one partial row for
+// htrvt_bn_finalize); partial: float32 [htrvt_stem_stats_rows(B, H)][64] workspace
+extern "C" int htrvt_stem_stats(const void* img, const float* stats, const float* w, float* partial, float* colstats, int B,
+                                int H, int W, int C, int img_u8, void* stream) {
+  HTRVT_REQUIRE(img && stats && w && partial && colstats, "htrvt_stem_stats: null argument");
+  HTRVT_REQUIRE(B > 0 && H >= 2 && H % 2 == 0 && W > 0 && C > 0, "htrvt_stem_stats: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+  const size_t smem = (size_t)3 * (W + 2) * 4;
+  HTRVT_REQUIRE(smem <= 48 * 1024, "htrvt_stem_stats: W=%d too wide for the LDS row buffer", W);
+  const int nrows = B * (H / 2);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(stem_moments_kernel, dim3(nrows), dim3(NT), smem, st, img, stats, partial, H, W, img_u8);
+  hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(64 * SS_RL), 0, st, partial, nrows, w, colstats, C);
+  return check_launch("stem_stats");
+}
+
+// conv1 -> BatchNorm (scale / shift) -> ReLU -> max-pool in one pass over the image: y [B][Hp][W][C], idx (or NULL)
+extern "C" int htrvt_stem_fwd(const void* img, const float* stats, const float* w, const float* scale, const float* shift,
+                              void* y, uint8_t* idx, int B, int H, int W, int C, int dtype, int img_u8, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(img && stats && w && scale && shift && y, "htrvt_stem_fwd: null argument");
+  HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0 && H >= 4, "htrvt_stem_fwd: C=%d must be a multiple of %d and <= %d", C,
+                ch, NT * ch);
+  const int lanes = C / ch, nthr = (NT / lanes) * lanes;
+  const size_t smem = (size_t)7 * (W + 2) * 4;
+  HTRVT_REQUIRE(smem <= 64 * 1024, "htrvt_stem_fwd: W=%d too wide for the LDS row buffer", W);
+  const int Hc = H / 2, Hp = (Hc - 1) / 2 + 1;
+  dim3 grid(B * Hp);
+  if (dtype == HTRVT_BF16)
+    hipLaunchKernelGGL(stem_fused_fwd_kernel<bf16_t>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, scale, shift,
+                       (bf16_t*)y, idx, H, W, C, nthr, img_u8);
+  else
+    hipLaunchKernelGGL(stem_fused_fwd_kernel<float>, grid, dim3(NT), smem, (hipStream_t)stream, img, stats, w, scale, shift,
+                       (float*)y, idx, H, W, C, nthr, img_u8);
+  return check_launch("stem_fwd");
 }
 
 extern "C" int htrvt_bn_finalize(const float* partial, int rows, int C, float count, const float* gamma, const float* beta,

@@ -75,6 +75,11 @@ class Engine:
         self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
         self.fuse_bn_backward = True   # bf16: ReLU mask + BN-backward sums in the dgrad epilogue (False: separate pass)
         self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream
+        # conv1 + BN + ReLU + max-pool in one pass over the image (no conv1 tensor): the throughput path.  The float32 parity
+        # path keeps the two-kernel form by default -- its batch statistics are then summed over the conv outputs the way
+        # the reference sums them, which keeps the sign-level comparison of Adam's first updates against the reference
+        # trace (tests/test_train_iter_gpu.py) where it was; tests/test_stem_gpu.py runs the fused form in float32 too.
+        self.fuse_stem_forward = dtype == torch.bfloat16
         self.fused_attention = True    # bf16: one launch per direction, scores / probabilities never reach HBM (csrc/attention.hip)
         # strided conv dgrad = one launch per input-pixel parity class: independent launches (disjoint output pixels), so
         # they may run on separate streams -- an epilogue-only class (no tap reaches it) then overlaps an MFMA-heavy one
@@ -447,18 +452,35 @@ class Engine:
         # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
         stats = self._empty(B, 2, dtype=torch.float32)
         check(lib.htrvt_img_stats(ptr(img), ptr(stats), B, H * W, WHITEN_EPS, u8, st), "img_stats")
-        c1 = self._empty(B, H // 2, W, C1)
-        cs = self._empty(B * (H // 2) + 64, 2, C1, dtype=torch.float32) if train else self._empty(B * (H // 2), 2, C1, dtype=torch.float32)
         w1 = P["patch_embed.conv1.weight"]
-        check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, u8, st), "conv1_fwd")
-        sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W, save=save)
         Hp = (H // 2 - 1) // 2 + 1
         a = self._empty(B, Hp, W, C1)
         idx = torch.empty(B, Hp, W, C1, dtype=torch.uint8, device=self.dev) if save else None
-        check(lib.htrvt_bn_relu_maxpool(ptr(c1), ptr(sc), ptr(sf), ptr(a), ptr(idx), B, H // 2, W, C1, self.dti, st),
-              "bn_relu_maxpool")
+        # The conv1 tensor (1.6 GB at the bench shape) is needed only by the unfused backward of the stem; otherwise
+        # conv1 + BatchNorm + ReLU + max-pool run as ONE pass over the image, the batch statistics of a train-mode
+        # BatchNorm coming from the image's second moments (csrc/stem.hip: stem_moments / stem_stats / stem_fused_fwd).
+        fused_stem = self.fuse_stem_forward and (not save or (train and self.fuse_conv1_backward))
+        if fused_stem:
+            c1 = None
+            if train:
+                cs = self._empty(2, C1, dtype=torch.float32)
+                part = self._empty(lib.htrvt_stem_stats_rows(B, H), 64, dtype=torch.float32)
+                check(lib.htrvt_stem_stats(ptr(img), ptr(stats), ptr(w1), ptr(part), ptr(cs), B, H, W, C1, u8, st), "stem_stats")
+                sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, True, cs, 1, B * (H // 2) * W, save=save)
+            else:
+                sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, False, save=save)
+            check(lib.htrvt_stem_fwd(ptr(img), ptr(stats), ptr(w1), ptr(sc), ptr(sf), ptr(a), ptr(idx), B, H, W, C1, self.dti,
+                                     u8, st), "stem_fwd")
+        else:
+            c1 = self._empty(B, H // 2, W, C1)
+            cs = self._empty(B * (H // 2) + 64, 2, C1, dtype=torch.float32) if train else self._empty(B * (H // 2), 2, C1, dtype=torch.float32)
+            check(lib.htrvt_conv1_fwd(ptr(img), ptr(stats), ptr(w1), ptr(c1), ptr(cs), B, H, W, C1, self.dti, u8, st), "conv1_fwd")
+            sc, sf, mean, rstd = self.bn_coeffs(P, "patch_embed.bn1", C1, train, cs, B * (H // 2), B * (H // 2) * W, save=save)
+            check(lib.htrvt_bn_relu_maxpool(ptr(c1), ptr(sc), ptr(sf), ptr(a), ptr(idx), B, H // 2, W, C1, self.dti, st),
+                  "bn_relu_maxpool")
         if save:
             sv["img"], sv["stats"], sv["c1"], sv["bn1"], sv["idx"] = img, stats, c1, (sc, sf, mean, rstd), idx
+            sv["c1_shape"] = (B, H // 2, W, C1)
 
         if prefetched:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -756,7 +778,7 @@ class Engine:
         img, c1 = sv["img"], sv["c1"]
         u8 = 1 if img.dtype == torch.uint8 else 0
         sc, sf, mean, rstd = sv["bn1"]
-        _, Hh, W, C1 = c1.shape
+        _, Hh, W, C1 = sv["c1_shape"]
         if self.fuse_conv1_backward and self._bn_train:
             # Cin = 1: dW1, dgamma, dbeta from per-channel sums over the pooled gradient (csrc/conv1_bwd.hip)
             partial = self._empty(lib.htrvt_conv1_bwd_rows(B, 2 * Hh), lib.htrvt_conv1_bwd_row_floats(C1), dtype=torch.float32)

@@ -109,6 +109,18 @@ int htrvt_img_stats(const void* img, float* stats, int B, int HW, float eps, int
  * colstats[B*H/2][2][C] (one row per output image row). w: [C][9] float32. */
 int htrvt_conv1_fwd(const void* img, const float* stats, const float* w, void* out, float* colstats,
                     int B, int H, int W, int C, int dtype, int img_u8, void* stream);
+/* Fused stem forward (resnet18.py:74-77 with HTR_VT.py:224): conv1 (one input channel) -> BatchNorm -> ReLU ->
+ * max_pool2d(3, stride (2,1), pad 1) straight from the image; the conv1 tensor is never written.
+ * htrvt_stem_stats: per-channel (sum, sum of squares) of the conv1 output computed from 54 second moments of the image
+ *   (batch statistics of a train-mode BatchNorm without the tensor) -> colstats float32 [2][C], one partial row for
+ *   htrvt_bn_finalize(rows = 1, count = B * H/2 * W); partial: float32 [htrvt_stem_stats_rows(B, H)][64] workspace.
+ * htrvt_stem_fwd: y [B][Hp][W][C] in dtype (Hp = (H/2 - 1)/2 + 1), idx uint8 (arg-max 3*row + column, 15 = ReLU
+ *   closed; NULL to skip) -- same values and arg-max rule as htrvt_conv1_fwd + htrvt_bn_relu_maxpool. */
+int htrvt_stem_stats_rows(int B, int H);
+int htrvt_stem_stats(const void* img, const float* stats, const float* w, float* partial, float* colstats, int B, int H,
+                     int W, int C, int img_u8, void* stream);
+int htrvt_stem_fwd(const void* img, const float* stats, const float* w, const float* scale, const float* shift, void* y,
+                   uint8_t* idx, int B, int H, int W, int C, int dtype, int img_u8, void* stream);
 /* BN statistics from partial sums: train mode.  partial [rows][2][C]; count = #elements per channel.
  * Writes scale = gamma*rstd, shift = beta - mean*scale, saves mean/rstd, updates running stats
  * (momentum, unbiased running_var) when running_mean != NULL and adds 1 to *num_batches_tracked (int64, may be NULL). */

@@ -178,19 +178,22 @@ __global__ __launch_bounds__(NT) void conv1_fwd_kernel(const void* __restrict__ 
 // that htrvt_bn_finalize takes.  conv1_bwd.hip uses the same identities for the backward.
 constexpr int NMOM = 54;   // 9 tap sums + 45 upper-triangle tap products
 
-// one block per conv row (b, ho): partial[block][64] (54 used)
+// one block per MOM_R consecutive conv rows of one image: partial[block][64] (54 used); the 54 block reductions are
+// amortised over MOM_R rows
+constexpr int MOM_R = 4;
 __global__ __launch_bounds__(NT) void stem_moments_kernel(const void* __restrict__ img, const float* __restrict__ stats,
                                                           float* __restrict__ partial, int H, int W, int u8) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* rows = reinterpret_cast<float*>(smem_raw);  // [3][W+2]
+  float* rows = reinterpret_cast<float*>(smem_raw);  // [2 MOM_R + 1][W+2]
   __shared__ float red[NT / 64][NMOM];
-  const int Ho = H / 2;
-  const int b = blockIdx.x / Ho, ho = blockIdx.x - b * Ho;
+  const int Ho = H / 2, groups = (Ho + MOM_R - 1) / MOM_R;
+  const int b = blockIdx.x / groups, ho0 = (blockIdx.x - b * groups) * MOM_R;
+  const int nr = min(MOM_R, Ho - ho0);
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
   const int WP = W + 2;
-  for (int i = threadIdx.x; i < 3 * WP; i += NT) {
+  for (int i = threadIdx.x; i < (2 * nr + 1) * WP; i += NT) {
     const int r = i / WP, c = i - r * WP;
-    const int hi = 2 * ho - 1 + r, wi = c - 1;
+    const int hi = 2 * ho0 - 1 + r, wi = c - 1;
     float v = 0.f;
     if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (load_pixel(img, ((long long)b * H + hi) * W + wi, u8) - mean) * rstd;
     rows[i] = v;
@@ -199,12 +202,13 @@ __global__ __launch_bounds__(NT) void stem_moments_kernel(const void* __restrict
   float acc[NMOM];
 #pragma unroll
   for (int k = 0; k < NMOM; ++k) acc[k] = 0.f;
+  for (int q = 0; q < nr; ++q)
   for (int px = threadIdx.x; px < W; px += NT) {
     float x[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) x[r * 3 + c] = rows[r * WP + px + c];
+      for (int c = 0; c < 3; ++c) x[r * 3 + c] = rows[(2 * q + r) * WP + px + c];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       acc[t] += x[t];
@@ -727,7 +731,7 @@ extern "C" int htrvt_conv1_fwd(const void* img, const float* stats, const float*
   return check_launch("conv1_fwd");
 }
 
-extern "C" int htrvt_stem_stats_rows(int B, int H) { return B * (H / 2); }
+extern "C" int htrvt_stem_stats_rows(int B, int H) { return B * ((H / 2 + MOM_R - 1) / MOM_R); }
 
 // (sum, sum of squares) of the conv1 output per channel, from the image alone -> colstats [2][C] (one partial row for
 // htrvt_bn_finalize); partial: float32 [htrvt_stem_stats_rows(B, H)][64] workspace
@@ -735,9 +739,11 @@ extern "C" int htrvt_stem_stats(const void* img, const float* stats, const float
                                 int H, int W, int C, int img_u8, void* stream) {
   HTRVT_REQUIRE(img && stats && w && partial && colstats, "htrvt_stem_stats: null argument");
   HTRVT_REQUIRE(B > 0 && H >= 2 && H % 2 == 0 && W > 0 && C > 0, "htrvt_stem_stats: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
-  const size_t smem = (size_t)3 * (W + 2) * 4;
-  HTRVT_REQUIRE(smem <= 48 * 1024, "htrvt_stem_stats: W=%d too wide for the LDS row buffer", W);
-  const int nrows = B * (H / 2);
+  const size_t smem = (size_t)(2 * MOM_R + 1) * (W + 2) * 4;
+  HTRVT_REQUIRE(smem <= 160 * 1024, "htrvt_stem_stats: W=%d too wide for the LDS row buffer", W);
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int nrows = htrvt_stem_stats_rows(B, H);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(stem_moments_kernel, dim3(nrows), dim3(NT), smem, st, img, stats, partial, H, W, img_u8);
   hipLaunchKernelGGL(stem_stats_kernel, dim3(1), dim3(64 * SS_RL), 0, st, partial, nrows, w, colstats, C);
@@ -753,7 +759,11 @@ extern "C" int htrvt_stem_fwd(const void* img, const float* stats, const float* 
                 ch, NT * ch);
   const int lanes = C / ch, nthr = (NT / lanes) * lanes;
   const size_t smem = (size_t)7 * (W + 2) * 4;
-  HTRVT_REQUIRE(smem <= 64 * 1024, "htrvt_stem_fwd: W=%d too wide for the LDS row buffer", W);
+  HTRVT_REQUIRE(smem <= 160 * 1024, "htrvt_stem_fwd: W=%d too wide for the LDS row buffer", W);
+  if (smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  }
   const int Hc = H / 2, Hp = (Hc - 1) / 2 + 1;
   dim3 grid(B * Hp);
   if (dtype == HTRVT_BF16)

@@ -38,7 +38,7 @@ def _stem(cfg, sd, x, dtype, fused, train=True):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("W,D,u8", [(512, 64, False), (576, 256, False), (512, 768, True)])
+@pytest.mark.parametrize("W,D,u8", [(512, 64, False), (576, 256, False), (512, 768, True), (2048, 64, False)])
 def test_fused_stem_matches_the_two_kernel_form(dtype, W, D, u8):
     cfg = O.Config(80, (64, W), embed_dim=D, depth=1, num_heads=2 if D == 64 else 4)
     sd = O.init_state_dict(cfg, seed=5, randomize_affine=True)

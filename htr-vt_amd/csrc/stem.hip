@@ -317,6 +317,7 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
   // channel pairs as 2-vectors: the 27 FMAs of a (column, channel) become v_pk_fma_f32 over two channels (same
   // per-channel operation order as conv1_fwd_kernel, so the float32 values are identical)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr bool KEYED = sizeof(T) == 2;   // bfloat16 output: see below
   f32x2 wr[CH / 2][9], sc[CH / 2], sf[CH / 2];
 #pragma unroll
   for (int j = 0; j < CH / 2; ++j) {
@@ -324,6 +325,10 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
     for (int t = 0; t < 9; ++t) wr[j][t] = f32x2{w[(cg * CH + 2 * j) * 9 + t], w[(cg * CH + 2 * j + 1) * 9 + t]};
     sc[j] = f32x2{scale[cg * CH + 2 * j], scale[cg * CH + 2 * j + 1]};
     sf[j] = f32x2{shift[cg * CH + 2 * j], shift[cg * CH + 2 * j + 1]};
+    if constexpr (KEYED) {   // the BatchNorm scale rides in the weights, the shift is the accumulator's start value
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[j][t] *= sc[j];
+    }
   }
   // conv row k of this pooled row = conv row 2 ph - 1 + k; rows outside the conv output are pooling padding (-inf)
   bool rowok[3];
@@ -332,18 +337,26 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
   // the two previous columns' (maximum, its row)
   float pv[2][CH];
   int pr[2][CH];
+  // KEYED (bfloat16 output): a candidate is ONE signed key -- the float32 bits of the pre-ReLU value with the low four
+  // mantissa bits replaced by (2 - row) << 2 | (2 - column) -- so the first maximum in scan order is a plain integer max
+  // (v_max3_i32) instead of compare + select chains, and the ReLU is the key 0 every maximum starts from (negative
+  // floats are negative integers).  Values closer than 16 float32 ulps count as equal, which the bfloat16 result
+  // cannot see.  The float32 path keeps the exact rule.
+  int pk[2][CH];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       pv[q][j] = -INFINITY;
       pr[q][j] = 0;
+      pk[q][j] = 0;
     }
   T* yrow = y + ((long long)blockIdx.x * W) * C + cg * CH;
   unsigned char* irow = idx ? idx + ((long long)blockIdx.x * W) * C + cg * CH : nullptr;
   for (int c = w0 - 1; c <= w1; ++c) {   // conv column c; the output of column c - 1 is complete once c is known
     float cv[CH];
     int cr[CH];
+    int ck[CH];
     if (c >= 0 && c < W) {
       float xin[7][3];
 #pragma unroll
@@ -354,28 +367,34 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
       for (int j = 0; j < CH / 2; ++j) {
         float m[2] = {-INFINITY, -INFINITY};
         int mr[2] = {0, 0};
+        int mk[2] = {0, 0};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           if (!rowok[k]) continue;   // block-uniform: pooling padding above the first / below the last conv row
-          f32x2 a = {0.f, 0.f};
+          f32x2 a = KEYED ? sf[j] : f32x2{0.f, 0.f};
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             const float xv = xin[2 * k + t / 3][t % 3];
             a = __builtin_elementwise_fma(wr[j][t], f32x2{xv, xv}, a);
           }
-          const f32x2 bn = __builtin_elementwise_fma(a, sc[j], sf[j]);
+          const f32x2 bn = KEYED ? a : __builtin_elementwise_fma(a, sc[j], sf[j]);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const float v = fmaxf(bn[e], 0.f);
-            const bool take = v > m[e];
-            m[e] = take ? v : m[e];
-            mr[e] = take ? k : mr[e];
+            if constexpr (KEYED) {
+              mk[e] = max(mk[e], (int)((__float_as_uint(bn[e]) & ~0xFu) | ((2u - k) << 2)));
+            } else {
+              const float v = fmaxf(bn[e], 0.f);
+              const bool take = v > m[e];
+              m[e] = take ? v : m[e];
+              mr[e] = take ? k : mr[e];
+            }
           }
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           cv[2 * j + e] = m[e];
           cr[2 * j + e] = mr[e];
+          ck[2 * j + e] = mk[e];
         }
       }
     } else {
@@ -383,6 +402,7 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
       for (int j = 0; j < CH; ++j) {
         cv[j] = -INFINITY;
         cr[j] = 0;
+        ck[j] = 0;
       }
     }
     const int wo = c - 1;
@@ -391,6 +411,13 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
       unsigned am[CH];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
+        if constexpr (KEYED) {
+          const unsigned best = (unsigned)max(max(pk[0][j] | 2, pk[1][j] | 1), ck[j]);   // >= 0: the ReLU
+          const float mv = __uint_as_float(best & ~0xFu);
+          o.set(j, mv);
+          am[j] = !(mv > 0.f) ? 15u : 3u * (2u - ((best >> 2) & 3u)) + (2u - (best & 3u));
+          continue;
+        }
         float m = pv[0][j];
         int r = pr[0][j], col = 0;
         // a later column wins only with a larger value, or an equal one in an EARLIER row (row-major scan order)
@@ -423,6 +450,8 @@ __global__ __launch_bounds__(NT) void stem_fused_fwd_kernel(const void* __restri
       pr[0][j] = pr[1][j];
       pv[1][j] = cv[j];
       pr[1][j] = cr[j];
+      pk[0][j] = pk[1][j];
+      pk[1][j] = ck[j];
     }
   }
 }

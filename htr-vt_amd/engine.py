@@ -93,6 +93,7 @@ class Engine:
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
         self._side, self._side_active = None, False
+        self._call_started = None      # event at the start of the previous forward() (host run-ahead throttle)
         self.saved = None
         self._bn_train = True
         self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
@@ -425,6 +426,17 @@ class Engine:
         u8 = 1 if img.dtype == torch.uint8 else 0    # uint8 pixels are read as value / 255 (ToTensor) by the first kernels
         B, _, H, W = img.shape
         assert (H, W) == (s.H, s.W), f"model built for {s.H}x{s.W}, got {H}x{W}"
+        # Host run-ahead throttle: enqueueing a step takes ~6 ms of host time against ~40 ms on the device, and nothing in
+        # a step makes the host wait.  Unbounded, the host queues many steps; every step's activations are then alive at
+        # once (the caching allocator cannot reuse a block before the streams that touched it have passed its
+        # record_stream events), the pool grows from 20 to ~96 GiB and the hundreds of device allocations that takes land
+        # in the middle of the run (measured: 120 ms per step for the first ten steps after warm-up).  So: before
+        # enqueueing call k the host waits until the device has STARTED call k-1 -- one call of run-ahead, which is all
+        # the device needs to never run dry.
+        if self._call_started is not None:
+            self._call_started.synchronize()
+        self._call_started = torch.cuda.Event()
+        self._call_started.record()
         st = stream()
         sv = {} if save else None
         C1 = s.D // 4

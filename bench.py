@@ -43,6 +43,12 @@ def parse():
                     help="weak: --batch images per GPU; strong: --batch images in total, split evenly over the ranks")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    # model size: create_model's constants (HTR_VT.py:244-254) by default; BASELINE configs 1 / 5 name other sizes, which
+    # the reference reaches through MaskedAutoencoderViT(...) directly (HTR_VT.py:143-151)
+    ap.add_argument("--embed-dim", type=int, default=768)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--heads", type=int, default=6)
+    ap.add_argument("--nb-cls", type=int, default=80)
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
     ap.add_argument("--sam", action="store_true", help="the reference's full iteration (train.py:119-128): SAM(AdamW) = two "
                     "fwd+bwd passes + climb/restore + AdamW + ModelEma update; images/s counts each image once")
@@ -53,7 +59,8 @@ def parse():
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: separate BatchNorm-backward reduction pass")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: conv1 tensor materialised (conv1_fwd + bn_relu_maxpool) "
-                    "instead of the one-pass stem forward")
+                    "instead of the one-pass stem forward (the bf16 default; the float32 parity path never fuses unless --fuse-stem)")
+    ap.add_argument("--fuse-stem", action="store_true", help="one-pass stem forward also on the float32 path")
     ap.add_argument("--deterministic", action="store_true", help="A/B: split-K weight gradients through ordered slabs instead "
                     "of float atomics also on the bf16 path (the float32 path always does)")
     ap.add_argument("--parallel-classes", action="store_true", help="A/B: parity-class dgrad launches of a strided conv on separate streams")
@@ -86,9 +93,9 @@ def cpu_baseline(args, mask):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 32))        # a 1-GPU box share is ~16 cores; more threads than cores only thrash
     torch.set_num_threads(cores)
-    cfg = O.Config(80, (64, args.width), embed_dim=768, depth=4, num_heads=6)
+    cfg = O.Config(args.nb_cls, (64, args.width), embed_dim=args.embed_dim, depth=args.depth, num_heads=args.heads)
     sd = O.init_state_dict(cfg, seed=123)
-    x, tg, tl = synthetic_batch(args.cpu_batch, 64, args.width, 80, cfg.num_patches, seed=0)
+    x, tg, tl = synthetic_batch(args.cpu_batch, 64, args.width, args.nb_cls, cfg.num_patches, seed=0)
     times = []
     for it in range(args.cpu_iters + 1):
         t0 = time.perf_counter()
@@ -100,10 +107,26 @@ def cpu_baseline(args, mask):
             O.loss_and_grads(sd, cfg, x, tg, tl, keep_mask=mask, train=True)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
-    return {"value": round(args.cpu_batch / t, 3), "unit": "line-images/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_iters} timed iterations (1 warm-up) of batch {args.cpu_batch} 64x{args.width}, "
-                      f"{'eval forward + log_softmax' if args.forward_only else 'fwd+CTC+bwd (torch autograd over the oracle)'}"
-                      f", torch CPU float32, {cores} threads"}
+    out = {"value": round(args.cpu_batch / t, 3), "unit": "line-images/s", "cores": cores, "kind": "port",
+           "sample": f"{args.cpu_iters} timed iterations (1 warm-up) of batch {args.cpu_batch} 64x{args.width}, "
+                     f"d{args.embed_dim}/{args.depth}L/{args.heads}h, "
+                     f"{'eval forward + log_softmax' if args.forward_only else 'fwd+CTC+bwd (torch autograd over the oracle)'}"
+                     f", torch CPU float32, {cores} threads"}
+    # SURVEY.md 8(d)'s CPU case beside it: BASELINE config 1 (the reference's own CPU-runnable shape, run/iam.sh: 64x512,
+    # batch 8) at d256/4L/4h and at create_model's d768/4L/6h, training step, a few seconds of host work
+    cfg1 = {}
+    for tag, (D_, L_, h_) in (("d256_4L_4h", (256, 4, 4)), ("d768_4L_6h", (768, 4, 6))):
+        c1 = O.Config(80, (64, 512), embed_dim=D_, depth=L_, num_heads=h_)
+        sd1 = O.init_state_dict(c1, seed=123)
+        x1, tg1, tl1 = synthetic_batch(8, 64, 512, 80, c1.num_patches, seed=0)
+        ts = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            O.loss_and_grads(sd1, c1, x1, tg1, tl1, keep_mask=None, train=True)
+            ts.append(time.perf_counter() - t0)
+        cfg1[tag] = round(8 / (sum(ts[1:]) / 2), 2)
+    out["config1_64x512_b8_train_images_per_s"] = cfg1
+    return out
 
 
 def parity_path(args, dev, x, tg, tl, keep):
@@ -113,7 +136,7 @@ def parity_path(args, dev, x, tg, tl, keep):
     from htrvt_amd.model import HTR_VT
     from htrvt_amd.trainer import Trainer
     torch.manual_seed(123)
-    model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=torch.float32).to(dev).train()
+    model = build_model(args, torch.float32).to(dev).train()
     tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=False)
     steps = 3
     tr.step(x, tg, tl, keep_mask=keep)
@@ -126,6 +149,26 @@ def parity_path(args, dev, x, tg, tl, keep):
     return {"dtype": "f32", "ms_per_step": round(dt * 1e3, 2), "value": round(x.shape[0] / dt, 1), "unit": "line-images/s",
             "steps": steps, "loss": float(loss.item()),
             "note": "float32 parity path (logits within 1e-3 of the reference, tests/test_full_shape_gpu.py), same step and batch"}
+
+
+def set_stem_fusion(eng, args):
+    """the engine's default (fused on bf16, two-kernel form on the float32 parity path) unless a flag overrides it"""
+    if args.no_fuse_stem:
+        eng.fuse_stem_forward = False
+    elif args.fuse_stem:
+        eng.fuse_stem_forward = True
+
+
+def build_model(args, dtype):
+    """create_model(nb_cls, [64, W]) (HTR_VT.py:244-254) -- or, for another width / depth / head count, the constructor it
+    wraps with the same patch size, MLP ratio and LayerNorm eps"""
+    from functools import partial
+    from htrvt_amd.model import HTR_VT
+    if (args.embed_dim, args.depth, args.heads) == (768, 4, 6):
+        return HTR_VT.create_model(nb_cls=args.nb_cls, img_size=[64, args.width], compute_dtype=dtype)
+    return HTR_VT.MaskedAutoencoderViT(args.nb_cls, img_size=[64, args.width], patch_size=(4, 64), embed_dim=args.embed_dim,
+                                       depth=args.depth, num_heads=args.heads, mlp_ratio=4,
+                                       norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), compute_dtype=dtype)
 
 
 def spawn_ranks(n):
@@ -175,13 +218,13 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(123)                                                  # option.py default --seed 123
-    model = HTR_VT.create_model(nb_cls=80, img_size=[64, args.width], compute_dtype=dtype).to(dev)
+    model = build_model(args, dtype).to(dev)
     N = model.num_patches
     B = args.batch
     if args.scaling == "strong":
         assert args.batch % world == 0, f"strong scaling: --batch {args.batch} must divide over {world} ranks"
         B = args.batch // world
-    x, tg, tl = synthetic_batch(B, 64, args.width, 80, N, seed=rank)
+    x, tg, tl = synthetic_batch(B, 64, args.width, args.nb_cls, N, seed=rank)
     x = x.to(dev)
     torch.manual_seed(7)
     keep = model.generate_span_mask(N, 0.4, 8)                              # run/iam.sh: --mask-ratio 0.4 --max-span-length 8
@@ -189,7 +232,7 @@ def main():
     if args.forward_only:
         model.eval()
         eng = model._engine(dev)
-        eng.fuse_stem_forward = not args.no_fuse_stem
+        set_stem_fusion(eng, args)
         P = dict(model.state_dict(keep_vars=True))
 
         def one_step():
@@ -202,7 +245,7 @@ def main():
                      use_collectives=use_dist and (world > 1 or args.rehearse_collectives))
         tr.engine.fuse_bn_backward = not args.no_fuse_bn
         tr.engine.overlap_wgrad = not args.no_overlap_wgrad
-        tr.engine.fuse_stem_forward = not args.no_fuse_stem
+        set_stem_fusion(tr.engine, args)
         tr.engine.deterministic = tr.engine.deterministic or args.deterministic
         tr.engine.fused_attention = not args.no_fused_attention
         tr.engine.parallel_classes = args.parallel_classes
@@ -302,16 +345,22 @@ def main():
                 "all_mfma_tflops": round(sum(r[2] * len(prof[r[1]]["events"]) for r in rows) / sum(r[0] for r in rows) / 1e9, 1)}
 
     if rank == 0:
-        out = {"metric": "line-images/sec (64x1024, B=128) fwd+bwd+CTC", "value": round(value, 1), "unit": "line-images/s",
+        model_tag = f"d{args.embed_dim}/{args.depth}L/{args.heads}h, nb_cls {args.nb_cls}"
+        what = ("fwd+CTC (eval)" if args.forward_only else "SAM(AdamW) 2x(fwd+bwd+CTC)+EMA" if args.sam else "fwd+bwd+CTC")
+        eng_ = eng if args.forward_only else tr.engine
+        out = {"metric": f"line-images/sec (64x{args.width}, B={B * world if args.scaling == 'strong' else B}) {what}",
+               "value": round(value, 1), "unit": "line-images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": ("HTR-VT base eval forward + CTC loss" if args.forward_only else
-                                        "HTR-VT base (d768/4L/6h, nb_cls 80) reference iteration: SAM(AdamW) 2x(fwd + CTC + bwd) + EMA"
+               "config": {"workload": (f"HTR-VT ({model_tag}) eval forward + CTC loss" if args.forward_only else
+                                        f"HTR-VT ({model_tag}) reference iteration: SAM(AdamW) 2x(fwd + CTC + bwd) + EMA"
                                         if args.sam else
-                                        "HTR-VT base (d768/4L/6h, nb_cls 80) training step: fwd + fused CTC + bwd + AdamW"
+                                        f"HTR-VT ({model_tag}) training step: fwd + fused CTC + bwd + AdamW"
                                         + (" + RCCL grad all-reduce" if world > 1 else "")),
                           "image": f"1x64x{args.width}", "batch_per_gpu": B, "global_batch": B * world,
                           "tokens_per_image": N, "mask": "span 0.4/8 (run/iam.sh)", "parallelism": f"dp{world}",
+                          "engine_flags": {k: getattr(eng_, k) for k in ("fuse_stem_forward", "fuse_bn_backward", "overlap_wgrad",
+                                                                          "fused_attention", "deterministic", "parallel_classes")},
                           "loss": float(loss.mean().item()) if loss is not None else None},
                "roofline": roof}
         if (not args.no_parity_path and world == 1 and args.dtype == "bf16" and not args.forward_only and not args.sam

@@ -43,6 +43,7 @@ __device__ int coeffs(int in_size, int out_size, int xx, int* kk, int kstride, i
   int xmax = (int)(center + support + 0.5);
   if (xmax > in_size) xmax = in_size;
   xmax -= xmin;
+  if (xmax > KSMAX) xmax = KSMAX;   // never past the tap table (over-scale images are blanked by the callers, see over_scale)
   double ww = 0.0;
   for (int x = 0; x < xmax; ++x) ww += bicubic((x + xmin - center + 0.5) * ss);
   for (int x = 0; x < xmax; ++x) {
@@ -64,6 +65,15 @@ __device__ __forceinline__ int thumb_width(int h, int w, int H, int W) {   // np
   return y < W ? y : W;
 }
 
+// An image that shrinks by more than htrvt_line_max_scale() needs more taps than the LDS tables hold.  The table lives in
+// device memory, so the host entry point cannot reject it: such an image (and a degenerate one: h, w or width' < 1) is
+// rendered as an empty line -- all 255, the pad value -- instead of overrunning the tables.  htrvt_amd.prepare_lines
+// raises before it gets here.
+__device__ __forceinline__ bool over_scale(int h, int w, int H, int ow) {
+  constexpr int MAXS = (KSMAX - 1) / 4;
+  return h < 1 || w < 1 || ow < 1 || h > MAXS * H || w > MAXS * ow;
+}
+
 // horizontal pass: tmp[row][xx] for row < h, xx < width'
 __global__ __launch_bounds__(NT) void line_hpass_kernel(const unsigned char* __restrict__ src,
                                                         const HtrvtLineImage* __restrict__ table,
@@ -71,10 +81,10 @@ __global__ __launch_bounds__(NT) void line_hpass_kernel(const unsigned char* __r
   __shared__ int kk[KSMAX * NT];     // [tap][thread]: conflict-free
   const HtrvtLineImage e = table[blockIdx.z];
   const int row0 = blockIdx.y * RPB;
-  if (row0 >= e.h) return;
+  if (row0 >= e.h || e.h < 1) return;
   const int ow = thumb_width(e.h, e.w, H, W);
   const int xx = blockIdx.x * NT + threadIdx.x;
-  if (blockIdx.x * NT >= ow) return;
+  if (blockIdx.x * NT >= ow || over_scale(e.h, e.w, H, ow)) return;
   const unsigned char* s = src + e.src_offset;
   unsigned char* t = tmp + e.tmp_offset;
   const int row1 = min(e.h, row0 + RPB);
@@ -100,7 +110,8 @@ __global__ __launch_bounds__(NT) void line_vpass_kernel(const HtrvtLineImage* __
                                                         unsigned char* __restrict__ dst, int H, int W) {
   extern __shared__ int vk[];        // [H][KSMAX + 2]: xmin, count, taps
   const HtrvtLineImage e = table[blockIdx.z];
-  const int ow = thumb_width(e.h, e.w, H, W);
+  int ow = e.h >= 1 ? thumb_width(e.h, e.w, H, W) : 0;
+  if (over_scale(e.h, e.w, H, ow)) ow = 0;      // blank line
   const int x = blockIdx.x * NT + threadIdx.x;
   unsigned char* d = dst + (long long)blockIdx.z * H * W;
   if (blockIdx.x * NT >= ow) {       // the whole block is padding

@@ -76,6 +76,24 @@ def get_2d_sincos_pos_embed(embed_dim, grid_size):
     return np.concatenate([np.sin(w), np.cos(w), np.sin(h), np.cos(h)], axis=1)
 
 
+class LayerNorm(nn.Module):
+    """the reference's parameter-free whitening over everything but the batch dimension (HTR_VT.py:134-136, eps 1e-5):
+    `model.layer_norm`.  Inside the model both of its uses are fused into kernels (input: htrvt_img_stats + the first
+    convolution; logits: htrvt_seq_whiten_fwd); called on its own it runs the same per-sample whitening kernel."""
+
+    def forward(self, x):
+        from htrvt_amd._lib import check, lib
+        from htrvt_amd.ops import ptr, stream
+        if not x.is_cuda:
+            raise RuntimeError("htrvt_amd runs on an MI355X only (no CPU / eager fallback exists)")
+        xf = x.detach().contiguous().float()
+        B = xf.shape[0]
+        y = torch.empty_like(xf)
+        stats = torch.empty(B, 2, dtype=torch.float32, device=xf.device)
+        check(lib.htrvt_seq_whiten_fwd(ptr(xf), ptr(y), ptr(stats), B, xf.numel() // B, 1e-5, 0, stream()), "seq_whiten_fwd")
+        return y
+
+
 class _HTRVTFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward and backward are HIP kernel sequences."""
 
@@ -90,6 +108,8 @@ class _HTRVTFunction(torch.autograd.Function):
         if need:
             ctx.saved_acts, eng.saved = eng.saved, None
             ctx.eng, ctx.names, ctx.P = eng, names, P
+        else:
+            ctx.mark_non_differentiable(y)     # nothing was kept for a backward: autograd must not ask for one
         return y
 
     @staticmethod
@@ -108,6 +128,7 @@ class MaskedAutoencoderViT(nn.Module):
     def __init__(self, nb_cls=80, img_size=[512, 32], patch_size=[8, 32], embed_dim=1024, depth=24, num_heads=16,
                  mlp_ratio=4., norm_layer=nn.LayerNorm, compute_dtype=torch.float32):
         super().__init__()
+        self.layer_norm = LayerNorm()           # parameter-free (HTR_VT.py:134-136,157): no state_dict entry
         self.patch_embed = resnet18.ResNet18(embed_dim)
         self.grid_size = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
         self.embed_dim = embed_dim
@@ -152,13 +173,24 @@ class MaskedAutoencoderViT(nn.Module):
             self._engines[key] = Engine(self._shape, self.compute_dtype, device)
         return self._engines[key]
 
-    def generate_span_mask(self, L, mask_ratio, max_span_length):
-        """keep-mask [L] (1 keep / 0 mask), same CPU-RNG draws as the reference (HTR_VT.py:202-210)."""
+    def generate_span_mask(self, x, mask_ratio, max_span_length):
+        """HTR_VT.py:202-210, same CPU-RNG draws.  x: the reference's [N, L, D] token tensor -> keep-mask [N, L, 1] on
+        x.device (1 keep / 0 mask, the same spans for every sample); or the sequence length L as an int -> the [L] mask
+        this model's forward hands to the token kernel."""
+        L = int(x) if isinstance(x, int) else x.shape[1]
         mask = torch.ones(L)
         for _ in range(int(L * mask_ratio) // max_span_length):
             idx = int(torch.randint(L - max_span_length, (1,)))
             mask[idx:idx + max_span_length] = 0
-        return mask
+        if isinstance(x, int):
+            return mask
+        return mask.view(1, L, 1).expand(x.shape[0], L, 1).contiguous().to(x.device)
+
+    def random_masking(self, x, mask_ratio, max_span_length):
+        """HTR_VT.py:212-220 for callers that hold a token tensor [N, L, D] themselves (the forks' heads do): the model's
+        own forward applies the mask inside htrvt_pool_tokens instead"""
+        mask = self.generate_span_mask(x, mask_ratio, max_span_length)
+        return x * mask + (1 - mask) * self.mask_token
 
     def forward(self, x, mask_ratio=0.0, max_span_length=1, use_masking=False, keep_mask=None):
         if not x.is_cuda:
@@ -172,6 +204,9 @@ class MaskedAutoencoderViT(nn.Module):
             tensors.append(t)
         # uint8 images (the data pipeline's raw grey levels) stay uint8: the first kernels read them as value / 255
         x = x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float()
+        if x.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("htrvt_amd computes no gradient with respect to the input image (d loss / d image): "
+                               "detach the image, or call under torch.no_grad()")
         need = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
         return _HTRVTFunction.apply(self, x, keep_mask, self.training, need, tuple(names), *tensors)
 

@@ -96,13 +96,19 @@ class FlatParams:
         with torch.cuda.stream(self.side):
             dist.all_reduce(self.flat_g[self.l3_start:self.enc_start])
 
-    def reduce_stem_bucket(self):
-        """the rest of the stem (conv1, layer1, layer2: 5.5 M weights), after the backward"""
+    def reduce_stem_bucket(self, producer=None):
+        """the rest of the stem (conv1, layer1, layer2: 5.5 M weights), after the backward: on the collective stream like
+        the other two buckets (one stream = one RCCL queue, the three all-reduces never interleave), and the current
+        stream then waits for all three -- the optimizer is the first consumer of any reduced gradient"""
         if not self.coll:
             return
-        dist.all_reduce(self.flat_g[:self.l3_start])
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+        if self.side is None:
+            dist.all_reduce(self.flat_g[:self.l3_start])
+            return
+        self._behind(producer)
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(self.flat_g[:self.l3_start])
+        torch.cuda.current_stream().wait_stream(self.side)
 
 
 class Trainer:

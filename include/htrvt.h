@@ -277,7 +277,8 @@ int htrvt_ctc_greedy_decode(const float* logits, int B, int T, int C, int64_t ld
  * right pad with 1.0 -- delivered as the uint8 batch dst [B][H][W] (255 = 1.0) that the model reads as value / 255.
  * src: all scans back to back; table[i] (device) = {byte offset of scan i in src, byte offset of its scratch rows in tmp
  * (h_i * W bytes each), h_i, w_i}; max_src_h = max h_i.  Every scale factor h_i / H and w_i / width' must be
- * <= htrvt_line_max_scale() (the tap table of one output pixel is bounded). */
+ * <= htrvt_line_max_scale() (the tap table of one output pixel is bounded); an image beyond it (or with h, w or width'
+ * < 1) is delivered as an empty line, all 255, never read past the table. */
 typedef struct HtrvtLineImage {
   int64_t src_offset;
   int64_t tmp_offset;

@@ -1,0 +1,93 @@
+"""BASELINE config 3 (data-parallel training step, RCCL gradient all-reduce) exercised on ONE MI355X: a fresh
+process creates a 1-rank `nccl` (= RCCL) process group before its first kernel and runs Trainer(use_collectives=True)
+-- the three bucketed all-reduces on their own stream, the waits on the engine's weight-gradient stream, the parameter /
+buffer broadcast -- beside Trainer(use_collectives=False).  A SUM all-reduce over one rank is the identity, so
+parameters, gradients and BatchNorm buffers after two AdamW steps and after one SAM(AdamW) iteration must agree BIT FOR
+BIT on the float32 path (deterministic reductions); any missing stream dependency shows up as a difference.
+SURVEY.md 8(e); the reference itself has no multi-GPU code (model_v1/train.py is single-process)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)      # before the first kernel of this process
+from functools import partial
+import htrvt_amd
+from htrvt_amd.model import HTR_VT
+from htrvt_amd.trainer import Trainer
+from oracle import htrvt_oracle as O                 # synthetic inputs only (test infrastructure)
+
+dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[sys.argv[2]]
+D, L, h = 256, 4, 4
+cfg = O.Config(80, (64, 512), embed_dim=D, depth=L, num_heads=h)
+x, tg, tl = O.synthetic_batch(8, 64, 512, 80, cfg.num_patches, seed=3)
+x = x.to(dev)
+
+
+def build(coll):
+    torch.manual_seed(123)
+    m = HTR_VT.MaskedAutoencoderViT(80, img_size=[64, 512], patch_size=(4, 64), embed_dim=D, depth=L, num_heads=h,
+                                    mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), compute_dtype=dtype)
+    m = m.to(dev).train()
+    tr = Trainer(m, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=coll)
+    tr.engine.deterministic = True        # slab split-K also on bf16: bitwise comparable runs
+    return m, tr
+
+
+def run(coll):
+    m, tr = build(coll)
+    torch.manual_seed(7)
+    k1 = m.generate_span_mask(cfg.num_patches, 0.4, 8)
+    k2 = m.generate_span_mask(cfg.num_patches, 0.4, 8)
+    out = []
+    for _ in range(2):
+        loss = tr.step(x, tg, tl, keep_mask=k1)
+        out.append(tr.flat.flat_g.clone())
+    out.append(tr.flat.flat_p.clone())
+    tr.sam_step(x, tg, tl, keep_mask=k1, keep_mask2=k2)
+    out.append(tr.flat.flat_g.clone())
+    out.append(tr.flat.flat_p.clone())
+    out += [b.clone() for _, b in m.named_buffers()]
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all()
+    return out, (tr.flat.side is not None)
+
+
+a, side_a = run(True)
+b, side_b = run(False)
+assert side_a and not side_b, "the collective run must own a collective stream"
+bad = [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
+assert not bad, f"collective / plain runs differ in tensors {bad}"
+assert float(a[0].abs().sum()) > 0
+dist.barrier()
+dist.destroy_process_group()
+print("DP1 OK", len(a), "tensors bit-identical")
+'''
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_trainer_collective_path_one_rank_nccl(dtype):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, dtype], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DP1 OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

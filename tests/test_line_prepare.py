@@ -55,6 +55,41 @@ def test_kernel_matches_fixtures_and_oracle(golden_dir):
 
 
 @pytest.mark.gpu
+def test_c_abi_over_scale_image_is_blanked_not_overrun():
+    """htrvt_line_prepare is a public C entry whose image table lives in device memory: an image that shrinks by more than
+    htrvt_line_max_scale() (more taps than the LDS tables hold) must come out as an empty line (all 255), and its
+    neighbours in the batch must be untouched -- prepare_lines() refuses such an image earlier, so go through the C ABI"""
+    import ctypes as C
+    from htrvt_amd._lib import check, lib
+    from htrvt_amd.data import _LineImage
+    from htrvt_amd.ops import ptr, stream
+    rng = np.random.default_rng(5)
+    H, W = 64, 256
+    smax = lib.htrvt_line_max_scale()
+    good = rng.integers(0, 256, (90, 300)).astype(np.uint8)
+    tall = rng.integers(0, 256, (H * (smax + 3), 200)).astype(np.uint8)      # vertical scale > smax
+    wide = rng.integers(0, 256, (64, 256 * (smax + 2))).astype(np.uint8)      # horizontal scale > smax (width' = W)
+    arrs = [good, tall, wide, good[::-1].copy()]
+    table = (_LineImage * len(arrs))()
+    so = to = 0
+    for i, a in enumerate(arrs):
+        table[i] = _LineImage(so, to, a.shape[0], a.shape[1])
+        so += a.size
+        to += a.shape[0] * W
+    src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in arrs])).cuda()
+    tab = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
+    tmp = torch.empty(to, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros(len(arrs), 1, H, W, dtype=torch.uint8, device="cuda")
+    check(lib.htrvt_line_prepare(ptr(src), ptr(tab), ptr(tmp), ptr(dst), len(arrs), H, W, max(a.shape[0] for a in arrs), stream()),
+          "line_prepare")
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[0, 0], L.prepare_line(good, W, H))
+    assert np.array_equal(got[3, 0], L.prepare_line(arrs[3], W, H))
+    assert (got[1] == 255).all() and (got[2] == 255).all()
+
+
+@pytest.mark.gpu
 def test_model_on_prepared_batch_equals_reference_loader_path():
     """loader semantics end to end: the float batch the reference builds on the host (resize, / 255, pad 1.0) and the
     uint8 batch of prepare_lines give the same logits bit for bit"""

@@ -90,3 +90,38 @@ def test_fused_stem_eval_mode_uses_running_statistics():
         with torch.no_grad():
             outs.append(eng.forward(P, x, train=False, save=False).cpu())
     assert (outs[0] - outs[1]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_fused_stem_statistics_on_smooth_padded_lines(u8):
+    """Real line scans are smooth strokes beside large areas padded with 1.0 (data/dataset.py:129-130), not white noise:
+    the image's second-moment matrix R is then far from diagonal, and for an edge (zero-sum) conv1 filter the batch
+    statistic sum y^2 = w^T R w is a difference of large, nearly equal entries.  Mean / rstd of the fused form
+    (htrvt_stem_stats) against the float64 evaluation of conv1 over the whitened image."""
+    import torch.nn.functional as F
+    cfg = O.Config(80, (64, 512), embed_dim=64, depth=1, num_heads=2)
+    sd = O.init_state_dict(cfg, seed=9, randomize_affine=True)
+    w = sd["patch_embed.conv1.weight"]
+    w[::2] -= w[::2].mean(dim=(1, 2, 3), keepdim=True)          # every other filter sums to zero: a pure edge detector
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(3, 1, 64, 512, generator=g)
+    for _ in range(3):                                           # low-pass: smooth strokes
+        x = F.avg_pool2d(F.pad(x, (4, 4, 4, 4), mode="replicate"), 9, stride=1)
+    x = (x - x.amin()) / (x.amax() - x.amin())
+    for b, cut in enumerate((200, 330, 512)):                    # ragged right padding with 1.0, one line unpadded
+        x[b, :, :, cut:] = 1.0
+    if u8:
+        x = (x * 255).round().to(torch.uint8)
+    got = _stem(cfg, sd, x.cuda(), torch.float32, fused=True)
+    xd = (x.double() / 255.0) if u8 else x.double()
+    if u8:
+        xd = (x.float() / 255.0).double()                        # the kernels read uint8 as float32 value / 255
+    xw = F.layer_norm(xd, xd.shape[1:], eps=1e-5)
+    y = F.conv2d(xw, w.double(), stride=(2, 1), padding=1)
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    _sc, _sf, gmean, grstd = got["bn"]
+    sd_ = var.sqrt()
+    assert ((gmean.double() - mean).abs() / (sd_ + 1e-3)).max().item() < 1e-4, ((gmean.double() - mean).abs() / (sd_ + 1e-3)).max().item()
+    assert ((grstd.double() - rstd).abs() / rstd).max().item() < 2e-4, ((grstd.double() - rstd).abs() / rstd).max().item()

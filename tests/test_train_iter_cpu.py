@@ -78,7 +78,7 @@ def check_iterations(res, g, strict_tol=2e-5, per_tensor_cos_min=0.98, f64=None,
       * f64 (an implementation with its own float32 rounding, i.e. the GPU): a tensor-by-tensor comparison of two
         float32 runs only measures those flips.  Instead the run must be as close to the float64 trace as the
         reference's own float32 run is: cosine over ALL parameters >= the reference's - 0.02, and every tensor of
-        >= 2048 elements >= the reference's - 0.05."""
+        >= 2048 elements >= the reference's - 0.05 (smaller tensors of >= 64 elements: - 0.15)."""
     lr = float(g["lr"])
     loss0, sd0, ema0 = res[0]
     assert abs(loss0 - float(g["it0.loss"])) < 1e-4 * abs(float(g["it0.loss"]))
@@ -126,6 +126,11 @@ def check_iterations(res, g, strict_tol=2e-5, per_tensor_cos_min=0.98, f64=None,
         for k, c in per_run.items():
             if sd1[k].numel() >= 2048:
                 assert c >= per_ref[k] - 0.05, (k, c, per_ref[k])
+            else:
+                # small tensors (conv1.weight, BatchNorm / LayerNorm affine parameters, biases; >= 64 elements): a looser
+                # floor, but a floor -- a sign or ordering bug confined to one of them in the second AdamW step would
+                # turn its update around (cosine near 0 or negative), which rounding-level flips never do
+                assert c >= per_ref[k] - 0.15, (k, c, per_ref[k])
     for k, v in ema1.items():
         ref = torch.from_numpy(g[f"it1.ema.{k}"])
         if v.dtype == torch.int64:

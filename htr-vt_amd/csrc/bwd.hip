@@ -736,6 +736,27 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
     dst[i] = from_f32<T>(src[i]);
 }
 
+// dst[r][c] = src[r][c] (optional) and dst_t[c][r] = src[r][c], both rounded to T; dst_t rows are ld_t long, columns
+// rows .. ld_t-1 are zero filled.  64 x 64 tiles through LDS: 256-byte global reads, 128-byte global writes.
+template <typename T>
+__global__ __launch_bounds__(NT) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t,
+                                                            int rows, int cols, int ld_t) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows of 64 threads
+  for (int rr = ty; rr < 64; rr += NT / 64) {
+    const int r = r0 + rr, c = c0 + tx;
+    const float v = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    tile[rr][tx] = v;
+    if (dst != nullptr && r < rows && c < cols) dst[(long long)r * cols + c] = from_f32<T>(v);
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += NT / 64) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (c < cols && r < ld_t) dst_t[(long long)c * ld_t + r] = from_f32<T>(tile[tx][cc]);   // rows >= `rows` were read as 0
+  }
+}
+
 // decoupled weight decay Adam over one flat float32 buffer (torch.optim.AdamW semantics)
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float decay, float w1, float b2,
@@ -969,6 +990,17 @@ extern "C" int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype,
   hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, src, (bf16_t*)dst,
                      (long long)n);
   return check_launch("cast_f32");
+}
+
+extern "C" int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows, int cols, int ld_t, int dtype,
+                                        void* stream) {
+  HTRVT_REQUIRE(dtype == HTRVT_BF16, "htrvt_cast_transpose_f32: only float32 -> bfloat16");
+  HTRVT_REQUIRE(src && dst_t && rows > 0 && cols > 0 && ld_t >= rows, "htrvt_cast_transpose_f32: bad arguments");
+  static_assert(NT == 256, "cast_transpose_kernel: 4 rows of 64 threads");
+  dim3 grid((cols + 63) / 64, (ld_t + 63) / 64);
+  hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, src, (bf16_t*)dst, (bf16_t*)dst_t, rows,
+                     cols, ld_t);
+  return check_launch("cast_transpose_f32");
 }
 
 extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

@@ -525,9 +525,12 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
 static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int zdim, hipStream_t st) {
   const bool cls = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0;
   const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
-  if (d->dtype == HTRVT_BF16 && d->tile != 1) {  // throughput path: LDS-DMA staged 256-row tiles (gemm_dma.hip)
+  if (d->dtype == HTRVT_BF16 && d->tile != 1) {  // throughput path: 256-row tiles, operands by LDS-DMA
     KParams q = p;
-    const int r = gemm_dma_try_launch(d, q, zdim, st);
+    int r = gemm8p_try_launch(d, q, zdim, st);   // 8-phase schedule, epilogue from the accumulators (gemm8p.hip)
+    if (r != 0) return r < 0 ? r : 0;
+    q = p;
+    r = gemm_dma_try_launch(d, q, zdim, st);     // one barrier per k-tile, LDS-staged epilogue (gemm_dma.hip)
     if (r != 0) return r < 0 ? r : 0;
   }
   HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");

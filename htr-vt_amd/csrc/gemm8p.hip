@@ -1,0 +1,96 @@
+// gemm8p.hip -- host-side selection of the 8-phase bfloat16 GEMM kernels (gemm8p_impl.h; instantiated in
+// gemm8p_plain.hip / gemm8p_conv.hip).  Called by htrvt_gemm (gemm.hip) before the older LDS-DMA kernels.
+#include "gemm_common.h"
+
+using namespace htrvt;
+
+namespace htrvt {
+int gemm8p_dispatch_plain(int bn, int epi, const KParams&, int, hipStream_t);
+int gemm8p_dispatch_conv(int bn, int gather, int epi, const KParams&, int, hipStream_t);
+}  // namespace htrvt
+
+namespace {
+
+constexpr int E_RES = 1, E_GELU = 2, E_GELUGRAD = 4, E_CSTATS = 8, E_RELUMASK = 16, E_BNB1 = 32, E_BNB2 = 64, E_F32 = 128,
+              E_SCALE_RELU = 256;
+
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+bool extents_ok(const HtrvtGemmDesc* d) {   // every byte offset the loaders form must stay below 2^31
+  const long long lim = (1ll << 31) - 64;
+  long long a, b = (long long)d->N * d->ldb * 2;
+  if (d->gather == HTRVT_GATHER_CONV_FWD) a = (long long)d->nB * d->Hi * d->Wi * d->Ci * 2;
+  else if (d->gather == HTRVT_GATHER_CONV_DGRAD) a = (long long)d->nB * d->Ho * d->Wo * d->Co * 2;
+  else a = (long long)d->M * d->lda * 2;
+  return a < lim && b < lim;
+}
+
+}  // namespace
+
+namespace htrvt {
+
+// tile selector (HtrvtGemmDesc.tile): 0 auto, 9 this family (auto width), 10 / 11 this family with 256 / 192 columns;
+// 1..8 and BM*1000+BN keep meaning the older kernels
+int gemm8p_pick_bn(const HtrvtGemmDesc* d) {
+  if (d->tile == 10) return 256;
+  if (d->tile == 11) return 192;
+  const long long p256 = (d->N + 255) / 256 * 256, p192 = (d->N + 191) / 192 * 192;
+  return p192 < p256 ? 192 : 256;
+}
+
+bool gemm8p_serves(const HtrvtGemmDesc* d) {
+  if (!(d->tile == 0 || (d->tile >= 9 && d->tile <= 11))) return false;
+  if (d->dtype != HTRVT_BF16 || d->M <= 128) return false;
+  if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
+  if (d->gather != HTRVT_GATHER_NONE && d->gather != HTRVT_GATHER_CONV_FWD && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;
+  if (d->split_k > 1 || d->accumulate || d->c_f32) return false;
+  if (!extents_ok(d)) return false;
+  const int bn = gemm8p_pick_bn(d);
+  const int cw = bn == 256 ? 8 : 12;     // consecutive columns a lane stores
+  if (d->N % cw) return false;
+  // 16-byte row pieces: rows and batch slices of C (and of every same-shaped side input) must start on 8-byte boundaries
+  // at least (the 24-byte pieces of the 192-column tile are dword-aligned dwordx4 + dwordx2 accesses)
+  if ((d->ldc & 3) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return false;
+  if (d->batch > 1 && ((d->sC_o | d->sC_i) & 3)) return false;
+  if (d->act == 2 && d->preact == nullptr) return false;
+  if ((d->colscale != nullptr || d->act == 3) && d->gather != HTRVT_GATHER_CONV_FWD) return false;
+  if ((d->relu_src != nullptr || d->bnb_partial[0] != nullptr) && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;
+  if (d->colstats != nullptr && d->gather != HTRVT_GATHER_CONV_FWD) return false;
+  if (d->act != 1 && d->act != 2 && d->preact != nullptr) return false;   // pre-activation without GELU: not built
+  return true;
+}
+
+// returns 1 if it launched, 0 if this family has no kernel for the call, < 0 on error
+int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
+  if (!gemm8p_serves(d)) return 0;
+  const int bn = gemm8p_pick_bn(d);
+  int epi = 0;
+  if (d->residual != nullptr) epi |= E_RES;
+  if (d->act == 1) epi |= E_GELU;
+  if (d->act == 2) epi |= E_GELUGRAD;
+  if (d->colstats != nullptr) epi |= E_CSTATS;
+  if (d->relu_src != nullptr) epi |= E_RELUMASK;
+  if (d->bnb_partial[0] != nullptr) epi |= E_BNB1;
+  if (d->bnb_partial[1] != nullptr) epi |= E_BNB2;
+  if (d->colscale != nullptr || d->act == 3) epi |= E_SCALE_RELU;
+  p.tiles_m = (d->M + 255) / 256;
+  p.tiles_n = (d->N + bn - 1) / bn;
+  p.wo_shift = p.howo_shift = -1;
+  p.wq_shift = p.hwq_shift = -1;
+  if (d->cls_h >= 0) {
+    const int a = ilog2_exact(p.Wq), b = ilog2_exact(p.Hq * p.Wq);
+    if (a >= 0 && b >= 0) {
+      p.wq_shift = a;
+      p.hwq_shift = b;
+    }
+  }
+  if (d->gather == HTRVT_GATHER_NONE) return gemm8p_dispatch_plain(bn, epi, p, zdim, st);
+  return gemm8p_dispatch_conv(bn, d->gather, epi, p, zdim, st);
+}
+
+}  // namespace htrvt

@@ -1,0 +1,25 @@
+// gemm8p_plain.hip -- instantiations of the 8-phase GEMM kernel for plain (Linear) operands: forward (bias, GELU +
+// saved pre-activation, residual) and dgrad against the transposed weight copy (plain, * GELU').  Own translation unit
+// (the Makefile builds the units in parallel).
+#include "gemm8p_impl.h"
+
+namespace htrvt {
+
+template <class C>
+static int by_epi(int epi, const KParams& p, int zdim, hipStream_t st) {
+  using namespace g8;
+  switch (epi) {
+    case 0: return launch<C, 0, 0>(p, zdim, st);
+    case E_RES: return launch<C, 0, E_RES>(p, zdim, st);
+    case E_GELU: return launch<C, 0, E_GELU>(p, zdim, st);
+    case E_GELUGRAD: return launch<C, 0, E_GELUGRAD>(p, zdim, st);
+    default: return 0;
+  }
+}
+
+int gemm8p_dispatch_plain(int bn, int epi, const KParams& p, int zdim, hipStream_t st) {
+  if (bn == 256) return by_epi<g8::Cfg<256, 2, 4>>(epi, p, zdim, st);
+  return by_epi<g8::Cfg<192, 4, 2>>(epi, p, zdim, st);
+}
+
+}  // namespace htrvt

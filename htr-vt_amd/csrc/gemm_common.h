@@ -207,5 +207,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[TM][TN], const P& 
 // defined in gemm_dma.hip: returns 1 if it launched, 0 if the shape is not one it serves, <0 on error
 int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st);
 int gemm_dma_num_mtiles(const HtrvtGemmDesc* d);
+// defined in gemm8p.hip (8-phase kernels, 256-row tiles): same return convention
+int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st);
 
 }  // namespace htrvt

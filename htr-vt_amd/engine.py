@@ -133,32 +133,39 @@ class Engine:
         return (t.data_ptr(), t._version, self.weights_epoch)
 
     def _lin_w(self, name, w):
-        """weight of a Linear in compute dtype ([out,in], unchanged layout)."""
+        """(weight, transposed weight) of a Linear in compute dtype: [out,in] for the forward GEMM and [in,out] for the
+        dgrad GEMM dx = dy @ w, so that both are K-major x K-major products on the same kernel.  float32: (w, None)."""
         if self.dtype == torch.float32:
-            return w
+            return w, None
         key = self._wkey(w)
         ent = self._packs.get(name)
         if ent is None or ent[0] != key:
-            buf = ent[1] if ent is not None else self._empty(*w.shape)
-            check(lib.htrvt_cast_f32(ptr(w), ptr(buf), w.numel(), self.dti, stream()), "cast_f32")
-            self._packs[name] = (key, buf)
-            return buf
+            out_f, in_f = w.shape
+            bufs = ent[1] if ent is not None else (self._empty(out_f, in_f), self._empty(in_f, out_f))
+            check(lib.htrvt_cast_transpose_f32(ptr(w), ptr(bufs[0]), ptr(bufs[1]), out_f, in_f, out_f, self.dti, stream()),
+                  "cast_transpose_f32")
+            self._packs[name] = (key, bufs)
+            return bufs
         return ent[1]
 
     def _head_w(self, w):
-        """head weight in compute dtype, rows zero-padded to a multiple of 8 classes ([Cp][D])."""
+        """head weight in compute dtype, rows zero-padded to a multiple of 8 classes: ([Cp][D], transposed [D][Cp] or None)"""
         C, D = w.shape
         Cp = (C + 7) // 8 * 8
         key = self._wkey(w)
         ent = self._packs.get("head")
         if ent is None or ent[0] != key:
-            buf = ent[1] if ent is not None else torch.zeros(Cp, D, dtype=self.dtype, device=self.dev)
             if self.dtype == torch.float32:
+                buf = ent[1][0] if ent is not None else torch.zeros(Cp, D, dtype=self.dtype, device=self.dev)
                 buf[:C].copy_(w)          # device memcpy
+                bufs = (buf, None)
             else:
-                check(lib.htrvt_cast_f32(ptr(w), ptr(buf), w.numel(), self.dti, stream()), "cast_f32")
-            self._packs["head"] = (key, buf)
-            return buf
+                bufs = ent[1] if ent is not None else (torch.zeros(Cp, D, dtype=self.dtype, device=self.dev),
+                                                       torch.zeros(D, Cp, dtype=self.dtype, device=self.dev))
+                check(lib.htrvt_cast_transpose_f32(ptr(w), ptr(bufs[0]), ptr(bufs[1]), C, D, Cp, self.dti, stream()),
+                      "cast_transpose_f32")
+            self._packs["head"] = (key, bufs)
+            return bufs
         return ent[1]
 
     def _conv_w(self, name, w):
@@ -190,12 +197,15 @@ class Engine:
              residual=residual, c_f32=c_f32)
         return out
 
-    def linear_dgrad(self, dy, w, act=0, preact=None):
-        """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(preact))."""
+    def linear_dgrad(self, dy, w, wt=None, act=0, preact=None):
+        """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(preact)).  wt = w^T [K][>=N] (bf16 path): K-major B operand."""
         M, N = dy.shape
         K = w.shape[1]
         dx = self._empty(M, K)
-        gemm(dy, w, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_layout=MNMAJOR, act=act, preact=preact)
+        if wt is not None:
+            gemm(dy, wt, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=wt.shape[1], ldc=K, act=act, preact=preact)
+        else:
+            gemm(dy, w, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_layout=MNMAJOR, act=act, preact=preact)
         return dx
 
     def _split_k(self, Mo, No, Kred, conv=False):
@@ -315,7 +325,7 @@ class Engine:
                     with torch.cuda.stream(st_):
                         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
                              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b),
-                             relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, tile=4 if (relu_src is not None or bnb) else 0)
+                             relu_src=relu_src, bnb=bnb, bnb_tile0=tile0)
                     tile0 += ops.gemm_num_mtiles(g.B * Hq * Wq, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
             for st_ in used:       # every class has written its pixels before anything downstream reads dx
                 main.wait_stream(st_)
@@ -566,7 +576,7 @@ class Engine:
         for i in range(s.depth):
             p = f"blocks.{i}"
             ln1, m1, r1 = self.ln_fwd(xt, P[p + ".norm1.weight"], P[p + ".norm1.bias"], save)
-            wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
+            wq, _ = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
             qkv = self.linear_fwd(ln1, wq, P[p + ".attn.qkv.bias"])
             O = self._empty(M, D)
             if self.fused_attention and lib.htrvt_attn_supported(N, hd, self.dti):
@@ -575,13 +585,13 @@ class Engine:
                 check(lib.htrvt_attn_fwd(ptr(qkv), None, ptr(O), ptr(lse), B, N, h, hd, scale, self.dti, st), "attn_fwd")
             else:
                 Pm, lse = self._attention_fwd_unfused(qkv, O, B, N, D, h, hd, scale, st), None
-            wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
+            wp, _ = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
             x1 = self.linear_fwd(O, wp, P[p + ".attn.proj.bias"], residual=xt)
             ln2, m2, r2 = self.ln_fwd(x1, P[p + ".norm2.weight"], P[p + ".norm2.bias"], save)
-            w1_ = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
+            w1_, _ = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
             hpre = self._empty(M, s.hidden) if save else None
             hact = self.linear_fwd(ln2, w1_, P[p + ".mlp.fc1.bias"], act=1, preact=hpre)
-            w2_ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
+            w2_, _ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
             x2 = self.linear_fwd(hact, w2_, P[p + ".mlp.fc2.bias"], residual=x1)
             if save:
                 enc_saved.append(dict(p=p, x0=xt, ln1=ln1, m1=m1, r1=r1, qkv=qkv, P=Pm, lse=lse, O=O, x1=x1, ln2=ln2, m2=m2, r2=r2,
@@ -590,7 +600,7 @@ class Engine:
 
         # --- norm + head + sequence LayerNorm (HTR_VT.py:236-239) ---
         xn, mn, rn = self.ln_fwd(xt, P["norm.weight"], P["norm.bias"], save)
-        wh = self._head_w(P["head.weight"])
+        wh, _ = self._head_w(P["head.weight"])
         raw = self._empty(M, s.nb_cls, dtype=torch.float32)
         gemm(xn, wh, raw, dtype=self.dtype, M=M, N=s.nb_cls, K=D, lda=D, ldb=D, ldc=s.nb_cls, bias=P["head.bias"], c_f32=True)
         y = self._empty(B, N, s.nb_cls, dtype=torch.float32)
@@ -658,8 +668,8 @@ class Engine:
         draw = torch.zeros(M, Cp, dtype=self.dtype, device=self.dev)
         check(lib.htrvt_seq_whiten_bwd(ptr(dy), ptr(sv["y"]), ptr(sv["sstats"]), ptr(draw), B, N, C, Cp, self.dti, st),
               "seq_whiten_bwd")
-        wh = self._head_w(P["head.weight"])
-        dxn = self.linear_dgrad(draw, wh)
+        wh, wht = self._head_w(P["head.weight"])
+        dxn = self.linear_dgrad(draw, wh, wht)
         if Cp == C:
             self.linear_wgrad(draw, sv["xn"], G["head.weight"], G["head.bias"])
         else:
@@ -673,18 +683,18 @@ class Engine:
         for e in reversed(sv["enc"]):
             p = e["p"]
             # MLP: x2 = x1 + fc2(gelu(fc1(ln2)))
-            w2_ = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
-            dhpre = self.linear_dgrad(dx, w2_, act=2, preact=e["hpre"])
+            w2_, w2t = self._lin_w(p + ".mlp.fc2", P[p + ".mlp.fc2.weight"])
+            dhpre = self.linear_dgrad(dx, w2_, w2t, act=2, preact=e["hpre"])
             self.linear_wgrad(dx, e["h"], G[p + ".mlp.fc2.weight"], G[p + ".mlp.fc2.bias"])
-            w1_ = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
-            dln2 = self.linear_dgrad(dhpre, w1_)
+            w1_, w1t = self._lin_w(p + ".mlp.fc1", P[p + ".mlp.fc1.weight"])
+            dln2 = self.linear_dgrad(dhpre, w1_, w1t)
             self.linear_wgrad(dhpre, e["ln2"], G[p + ".mlp.fc1.weight"], G[p + ".mlp.fc1.bias"])
             del dhpre
             dx1 = self.ln_bwd(dln2, e["x1"], e["m2"], e["r2"], P[p + ".norm2.weight"], dx, G[p + ".norm2.weight"],
                               G[p + ".norm2.bias"])
             # attention: x1 = x0 + proj(attn(ln1))
-            wp = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
-            dO = self.linear_dgrad(dx1, wp)
+            wp, wpt = self._lin_w(p + ".attn.proj", P[p + ".attn.proj.weight"])
+            dO = self.linear_dgrad(dx1, wp, wpt)
             self.linear_wgrad(dx1, e["O"], G[p + ".attn.proj.weight"], G[p + ".attn.proj.bias"])
             qkv, Pm = e["qkv"], e["P"]
             dqkv = self._empty(M, 3 * D)
@@ -694,8 +704,8 @@ class Engine:
                                          B, N, h, hd, scale, self.dti, st), "attn_bwd")
             else:
                 self._attention_bwd_unfused(qkv, Pm, dO, dqkv, B, N, D, h, hd, scale, st)
-            wq = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
-            dln1 = self.linear_dgrad(dqkv, wq)
+            wq, wqt = self._lin_w(p + ".attn.qkv", P[p + ".attn.qkv.weight"])
+            dln1 = self.linear_dgrad(dqkv, wq, wqt)
             self.linear_wgrad(dqkv, e["ln1"], G[p + ".attn.qkv.weight"], G[p + ".attn.qkv.bias"])
             dx = self.ln_bwd(dln1, e["x0"], e["m1"], e["r1"], P[p + ".norm1.weight"], dx1, G[p + ".norm1.weight"],
                              G[p + ".norm1.bias"])

@@ -239,6 +239,10 @@ int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int C
 /* grad [Co][Ci][taps] += packed [taps][cpad_in][Co]  (the conv-wgrad GEMM output) */
 int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in, void* stream);
 int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
+/* Linear weight w [rows = out][cols = in] float32 -> dst [rows][cols] (may be NULL) and dst_t [cols][ld_t] = w^T in
+ * `dtype` (bfloat16), columns rows .. ld_t-1 of dst_t zero: the K-major B operand of the Linear dgrad GEMM
+ * dx[M][in] = dy[M][out] * w (HTR_VT.py:22-37 backward), so that forward and dgrad run the same kernel. */
+int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows, int cols, int ld_t, int dtype, void* stream);
 
 /* ---- optimizer step (train.py:94 AdamW(betas .9/.99, wd .5) as one flat launch) -- */
 /* Statement order and rounding points of torch.optim.AdamW's single-tensor step; the hyper-parameters are doubles as in

@@ -1,0 +1,151 @@
+"""The 8-phase bfloat16 GEMM kernels (csrc/gemm8p_impl.h) behind htrvt_gemm: both tile widths forced through the `tile`
+selector (10: 256 columns, 2 x 4 waves; 11: 192 columns, 4 x 2 waves) on exact integer data -- tails in M, N and K,
+the direct-from-accumulator epilogues, the implicit-GEMM convolution gathers with their fused backward epilogues --
+and the older LDS-DMA family (tile 3 / 4) kept green beside it, since it still serves the MN-major and float32-output
+shapes.  References: float64 torch on the host (reference call sites: HTR_VT.py:22-37,76 Linear / timm Mlp,
+resnet18.py:26-31,59-63 convolutions)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import test_gemm_gpu as T
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _last_kernel():
+    from htrvt_amd._lib import lib
+    return lib.htrvt_last_kernel().decode()
+
+
+@pytest.fixture
+def force_tile(monkeypatch):
+    def set_(tile):
+        from htrvt_amd import ops
+        monkeypatch.setattr(ops, "_ENV_TILE", tile)
+    return set_
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (1000, 264, 200), (512, 3072, 768), (300, 96, 72), (4096, 2304, 64),
+                                   (260, 24, 1024), (129, 192, 8)])
+def test_plain_exact(tile, M, N, K):
+    ops = T._ops()
+    A, B = T._ints((M, K), seed=1), T._ints((N, K), seed=2)
+    ref = A @ B.t()
+    a, b = A.to(BF).cuda(), B.to(BF).cuda()
+    c = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+    ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
+    assert "gemm8p_kernel" in _last_kernel(), _last_kernel()
+    assert torch.equal(c.double().cpu(), ref.to(BF).double())
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+def test_plain_padded_leading_dimensions_and_batch(tile):
+    """lda / ldb / ldc larger than the row, a batch of independent products (batch strides), nothing outside C's columns written"""
+    ops = T._ops()
+    M, N, K, nb = 384, 192, 136, 3
+    A, B = T._ints((nb, M, K + 8), seed=3), T._ints((nb, N, K + 16), seed=4)
+    c = torch.full((nb, M, N + 24), 5.0, dtype=BF, device="cuda")
+    ops.gemm(A.to(BF).cuda(), B.to(BF).cuda(), c, dtype=BF, M=M, N=N, K=K, lda=K + 8, ldb=K + 16, ldc=N + 24, batch=nb,
+             batch_inner=1, sA=(M * (K + 8), 0), sB=(N * (K + 16), 0), sC=(M * (N + 24), 0), tile=tile)
+    assert "gemm8p_kernel" in _last_kernel()
+    ref = A[:, :, :K] @ B[:, :, :K].transpose(1, 2)
+    got = c.double().cpu()
+    assert torch.equal(got[:, :, :N], ref.to(BF).double())
+    assert (got[:, :, N:] == 5.0).all()
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+def test_linear_epilogues(tile):
+    """bias + exact-erf GELU + saved pre-activation (fc1 forward), bias + residual (proj / fc2 forward), * GELU'(saved)
+    (fc2 dgrad): random data against float64"""
+    ops = T._ops()
+    M, N, K = 520, 384, 192
+    g = torch.Generator().manual_seed(3)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a, b = A.to(BF), B.to(BF)
+    acc = a.double() @ b.double().t()
+    # GELU + preact
+    pre = acc * 0.5 + bias.double()
+    c = torch.empty(M, N, dtype=BF, device="cuda")
+    p = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1, bias=bias.cuda(), preact=p, tile=tile)
+    assert "gemm8p_kernel" in _last_kernel()
+    assert torch.equal(p.double().cpu(), pre.to(BF).double())                       # the saved value is the rounded pre-activation
+    assert (c.double().cpu() - F.gelu(pre.to(BF).double())).abs().max() < 2e-2     # GELU of the rounded value, rounded again
+    # GELU without a saved pre-activation
+    c2 = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), c2, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1, bias=bias.cuda(), tile=tile)
+    assert torch.equal(c2, c)
+    # residual: ONE rounding of acc + bias + residual
+    r = res.to(BF)
+    ops.gemm(a.cuda(), b.cuda(), c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.cuda(), residual=r.cuda(), tile=tile)
+    assert "gemm8p_kernel" in _last_kernel()
+    want = acc + bias.double() + r.double()
+    assert (c.double().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() * 1.01
+    # * GELU'(saved pre-activation)
+    xs = (torch.randn(M, N, generator=g) * 1.5).to(BF)
+    ops.gemm(a.cuda(), b.cuda(), c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=2, preact=xs.cuda(), tile=tile)
+    assert "gemm8p_kernel" in _last_kernel()
+    x64 = xs.double()
+    gp = 0.5 * (1 + torch.erf(x64 / 2 ** 0.5)) + x64 * torch.exp(-0.5 * x64 * x64) / (2 * torch.pi) ** 0.5
+    want = acc * gp
+    assert (c.double().cpu() - want).abs().max() <= 2.0 ** -7 * want.abs().max()
+
+
+@pytest.mark.parametrize("tile", [10, 11, 4])
+@pytest.mark.parametrize("cfg", T.CONVS)
+def test_conv_gathers_exact(force_tile, tile, cfg):
+    """implicit-GEMM conv forward (+ BatchNorm column sums), dgrad, parity-class dgrad + residual: the existing exact test with
+    the kernel family forced (shapes a width cannot serve fall back inside htrvt_gemm and stay exact)"""
+    force_tile(tile)
+    T.test_conv_fwd_dgrad_wgrad_exact(BF, cfg)
+
+
+@pytest.mark.parametrize("tile", [0, 11, 4])
+@pytest.mark.parametrize("cfg", T.FUSED_DGRAD)
+@pytest.mark.parametrize("nbn,with_res", [(1, False), (1, True), (2, True)])
+def test_conv_dgrad_fused_epilogues(force_tile, tile, cfg, nbn, with_res):
+    force_tile(tile)
+    T.test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res)
+    if tile != 4 and cfg[3] % 12 == 0:
+        assert "gemm8p_kernel" in _last_kernel(), _last_kernel()
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("M,N", [(512, 192), (1024, 384), (300, 768)])
+def test_conv_forward_eval_epilogue(tile, M, N):
+    """eval-mode BatchNorm folded into a (1x1) convolution launch: C = relu(acc * colscale[n] + bias[n] + residual), one rounding"""
+    ops = T._ops()
+    Ci = 64
+    Bn, Wd = 1, M
+    geom = ops.ConvGeom(Bn, 1, Wd, Ci, N, 1, (1, 1), 0)
+    A, B = T._ints((M, Ci), lo=-2, hi=3, seed=4), T._ints((N, Ci), lo=-2, hi=3, seed=5)
+    g = torch.Generator().manual_seed(6)
+    scale = torch.tensor([0.25, 0.5, 1.0, -0.5])[torch.randint(0, 4, (N,), generator=g)].double()
+    bias = torch.randint(-8, 9, (N,), generator=g).double()
+    res = torch.randint(-16, 17, (M, N), generator=g).double()
+    pre = (A @ B.t()) * scale + bias
+    for with_res, relu in ((False, False), (False, True), (True, True)):
+        ref = pre + (res if with_res else 0.0)
+        if relu:
+            ref = ref.clamp_min(0.0)
+        c = torch.empty(M, N, dtype=BF, device="cuda")
+        ops.gemm(A.to(BF).cuda(), B.to(BF).cuda(), c, dtype=BF, M=M, N=N, K=Ci, lda=Ci, ldb=Ci, ldc=N, gather=ops.GATHER_CONV_FWD,
+                 geom=geom, Cpad=Ci, colscale=scale.float().cuda(), bias=bias.float().cuda(),
+                 residual=res.to(BF).cuda() if with_res else None, act=3 if relu else 0, tile=tile)
+        assert "gemm8p_kernel" in _last_kernel(), _last_kernel()
+        assert torch.equal(c.double().cpu(), ref.to(BF).double()), (with_res, relu)
+
+
+def test_older_family_still_exact(force_tile):
+    """tile 3 / 4: the one-barrier-per-k-tile LDS-DMA kernels (still the path of MN-major operands and float32 outputs)"""
+    for tile in (3, 4):
+        force_tile(tile)
+        T.test_nt_plain_exact(BF, 512, 3072, 768)
+        assert "gemm_dma_kernel" in _last_kernel()
+        T.test_nt_epilogue(BF)

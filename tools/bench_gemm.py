@@ -137,6 +137,22 @@ def main():
         nn("NN dgrad-fc1 32768x768x3072", 32768, 768, 3072)
         nn("NN dgrad-qkv 32768x768x2304", 32768, 768, 2304)
         tn("TN wgrad-fc1 3072x768xK32768", 3072, 768, 32768, 8)
+    if "enc" in args.only:      # the encoder's Linear layers at B = 128, N = 256 tokens (M = 32768), forward and dgrad (K-major x K-major)
+        M, D, F3, F = 32768, 768, 2304, 3072
+        bq, bf, bd = torch.rand(F3, device=dev), torch.rand(F, device=dev), torch.rand(D, device=dev)
+        res = rnd(M, D)
+        pre = torch.empty(M, F, dtype=dt, device=dev)
+        pre_in = rnd(M, F)
+        plain("NT 4096^3", 4096, 4096, 4096)
+        plain("NT 8192^3", 8192, 8192, 8192)
+        plain("qkv fwd +bias        32768x2304x768", M, F3, D, bias=bq)
+        plain("proj fwd +bias+res   32768x768x768", M, D, D, bias=bd, residual=res)
+        plain("fc1 fwd +bias+gelu+pre 32768x3072x768", M, F, D, bias=bf, act=1, preact=pre)
+        plain("fc2 fwd +bias+res    32768x768x3072", M, D, F, bias=bd, residual=res)
+        plain("fc2 dgrad *gelu'     32768x3072x768", M, F, D, act=2, preact=pre_in)
+        plain("fc1 dgrad            32768x768x3072", M, D, F)
+        plain("qkv dgrad            32768x768x2304", M, D, F3)
+        plain("proj dgrad           32768x768x768", M, D, D)
     if not args.only or "mlp" in args.only:
         M, D, F = 32768, 768, 3072
         bias = torch.rand(F, device=dev)

@@ -27,7 +27,10 @@ bool extents_ok(const HtrvtGemmDesc* d) {   // every byte offset the loaders for
   if (d->gather == HTRVT_GATHER_CONV_FWD) a = (long long)d->nB * d->Hi * d->Wi * d->Ci * 2;
   else if (d->gather == HTRVT_GATHER_CONV_DGRAD) a = (long long)d->nB * d->Ho * d->Wo * d->Co * 2;
   else a = (long long)d->M * d->lda * 2;
-  return a < lim && b < lim;
+  // C and its same-shaped side inputs are addressed through 2 GiB buffer descriptors as well
+  const long long crows = (d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0) ? (long long)d->nB * d->Hi * d->Wi : d->M;
+  const long long c = crows * d->ldc * 2;
+  return a < lim && b < lim && c < lim;
 }
 
 }  // namespace

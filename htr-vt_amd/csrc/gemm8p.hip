@@ -42,12 +42,22 @@ namespace htrvt {
 int gemm8p_pick_bn(const HtrvtGemmDesc* d) {
   if (d->tile == 10) return 256;
   if (d->tile == 11) return 192;
-  const long long p256 = (d->N + 255) / 256 * 256, p192 = (d->N + 191) / 192 * 192;
-  return p192 < p256 ? 192 : 256;
+  // rounds of 256 workgroups x columns per tile; the 192-column tile costs ~12 % more per FLOP (12 instead of 16 MFMAs per
+  // phase, 14 % more operand bytes per FLOP).  Measured (tools/bench_gemm.py --only enc --tiles 4 10 11, M = 32768):
+  // N = 768 -> 192 (512 tiles = 2 full rounds; 256 columns: 384 tiles = 1.5), N = 2304 / 3072 -> 256
+  const long long tm = (d->M + 255) / 256;
+  auto cost = [&](int bn, double per_flop) {
+    const long long tiles = tm * ((d->N + bn - 1) / bn) * (d->batch > 1 ? d->batch : 1);
+    return (double)((tiles + 255) / 256) * bn * per_flop;
+  };
+  return cost(192, 1.12) < cost(256, 1.0) ? 192 : 256;
 }
 
 bool gemm8p_serves(const HtrvtGemmDesc* d) {
-  if (!(d->tile == 0 || (d->tile >= 9 && d->tile <= 11))) return false;
+  // auto (tile 0): the Linear shapes only.  The implicit-GEMM convolutions stay on the loader-wave kernels of
+  // gemm_dma_impl.h unless this family is asked for: with all eight waves forming gather addresses the k-tile is
+  // 15-25 % slower there (tools/bench_gemm.py --only conv --tiles 4 10 11: layer-1 forward 969 vs 813 TFLOP/s)
+  if (!((d->tile == 0 && d->gather == HTRVT_GATHER_NONE) || (d->tile >= 9 && d->tile <= 11))) return false;
   if (d->dtype != HTRVT_BF16 || d->M <= 128) return false;
   if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
   if (d->gather != HTRVT_GATHER_NONE && d->gather != HTRVT_GATHER_CONV_FWD && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;

@@ -104,12 +104,20 @@ struct ALoader {
   unsigned tapoff[2][C::NPW];   // gather: byte offset of (pixel reached through the current tap) + chunk, or OOB
   int ck;                       // element offset of this lane's chunk inside a k-tile (after the swizzle)
   int cur_ti;
+  int k0, ti, cbase;            // the k-tile the next half tile belongs to: first k, and (gathers) its tap position / channel base
   i32x4_t rsrc;
 
   template <class P>
-  __device__ __forceinline__ void init(const P& p, const char* base, int m0, int wave, int lane) {
+  __device__ __forceinline__ void init(const P& p, const char* base, int m0, int kbeg, int wave, int lane) {
     rsrc = make_rsrc(base);
     cur_ti = -1;
+    k0 = kbeg;
+    ti = 0;
+    cbase = 0;
+    if constexpr (GATHER != 0) {
+      ti = kbeg / p.Cpad;
+      cbase = kbeg - ti * p.Cpad;
+    }
     const int rl = lane >> 3;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -144,12 +152,12 @@ struct ALoader {
       }
   }
 
-  // per k-tile, before its first piece: tap bookkeeping of the gathers (wave-uniform branch, once per tap)
-  template <class P>
-  __device__ __forceinline__ void enter_ktile(const P& p, int k0) {
-    if constexpr (GATHER != 0) {
-      const int ti = k0 / p.Cpad;
-      if (ti != cur_ti) {
+  // half tile X of the current k-tile (half 0 is always issued before half 1; after half 1 the loader moves to the next
+  // k-tile).  Past kend: zero fill.
+  template <int X, class P>
+  __device__ __forceinline__ void issue(const P& p, unsigned lds_half, int kend, int wave) {
+    if constexpr (GATHER != 0 && X == 0) {
+      if (ti != cur_ti && k0 < kend) {   // wave-uniform: the k loop enters a new tap
         cur_ti = ti;
         const int tap = (int)((p.tappack >> (4 * ti)) & 15ull);
         const int dy = tap / p.kw, dx = tap - dy * p.kw;
@@ -174,23 +182,26 @@ struct ALoader {
           }
       }
     }
-  }
-
-  // issue half tile x of the k-tile that starts at k0 (k0 >= kend: zero fill)
-  template <int X, class P>
-  __device__ __forceinline__ void issue(const P& p, unsigned lds_half, int k0, int kend, int wave) {
 #pragma unroll
     for (int i = 0; i < C::NPW; ++i) {
       unsigned voff;
       if constexpr (GATHER == 0) {
         voff = (k0 + ck < kend) ? off0[X][i] + (unsigned)k0 * 2 : OOB;
       } else {
-        const int ti = k0 / p.Cpad;
-        const int cbase = k0 - ti * p.Cpad;
         const int cvalid = GATHER == 1 ? p.Ci : p.Co;
         voff = (k0 < kend && cbase + ck < cvalid) ? tapoff[X][i] + (unsigned)cbase * 2 : OOB;
       }
       dma16(rsrc, __builtin_amdgcn_readfirstlane(lds_half + (wave + 8 * i) * 1024), voff);
+    }
+    if constexpr (X == 1) {
+      k0 += BK;
+      if constexpr (GATHER != 0) {
+        cbase += BK;
+        if (cbase >= p.Cpad) {
+          cbase -= p.Cpad;
+          ++ti;
+        }
+      }
     }
   }
 };
@@ -201,11 +212,19 @@ template <class C, bool KMAP>
 struct BLoader {
   unsigned off0[2][C::NPW];
   int ck;
+  int k0, ti, cbase;
   i32x4_t rsrc;
 
   template <class P>
-  __device__ __forceinline__ void init(const P& p, const char* base, int n0, int wave, int lane) {
+  __device__ __forceinline__ void init(const P& p, const char* base, int n0, int kbeg, int wave, int lane) {
     rsrc = make_rsrc(base);
+    k0 = kbeg;
+    ti = 0;
+    cbase = 0;
+    if constexpr (KMAP) {
+      ti = kbeg / p.Cpad;
+      cbase = kbeg - ti * p.Cpad;
+    }
     const int rl = lane >> 3;
 #pragma unroll
     for (int y = 0; y < 2; ++y)
@@ -222,18 +241,27 @@ struct BLoader {
   }
 
   template <int Y, class P>
-  __device__ __forceinline__ void issue(const P& p, unsigned lds_half, unsigned lds_scratch, int k0, int kend, int wave) {
+  __device__ __forceinline__ void issue(const P& p, unsigned lds_half, unsigned lds_scratch, int kend, int wave) {
     int kcol = k0;
     if constexpr (KMAP) {
-      const int ti = k0 / p.Cpad;
-      const int tap = (int)((p.tappack >> (4 * ti)) & 15ull);
-      kcol = k0 - ti * p.Cpad + tap * p.Cpad;
+      const int tap = (int)((p.tappack >> (4 * (ti < 15 ? ti : 15))) & 15ull);
+      kcol = cbase + tap * p.Cpad;
     }
 #pragma unroll
     for (int i = 0; i < C::NPW; ++i) {
       const unsigned voff = (k0 + ck < kend) ? off0[Y][i] + (unsigned)kcol * 2 : OOB;
       const bool dm = (C::B_PIECES < 16) && (wave + 8 * i >= C::B_PIECES);      // wave-uniform
       dma16(rsrc, __builtin_amdgcn_readfirstlane(dm ? lds_scratch : lds_half + (wave + 8 * i) * 1024), voff);
+    }
+    if constexpr (Y == 1) {
+      k0 += BK;
+      if constexpr (KMAP) {
+        cbase += BK;
+        if (cbase >= p.Cpad) {
+          cbase -= p.Cpad;
+          ++ti;
+        }
+      }
     }
   }
 };
@@ -292,8 +320,8 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
 
   ALoader<C, GATHER> la;
   BLoader<C, GATHER != 0> lb;
-  la.init(p, Ab, m0, wave, lane);
-  lb.init(p, Bb, n0, wave, lane);
+  la.init(p, Ab, m0, kbeg, wave, lane);
+  lb.init(p, Bb, n0, kbeg, wave, lane);
 
   f32x4_t acc[2][2][MT][NT];
 #pragma unroll
@@ -315,29 +343,26 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
   const unsigned rdA = ra * 128 + ((fg ^ swz(ra)) << 4);
   const unsigned rdB = rb * 128 + ((fg ^ swz(rb)) << 4);
 
-  auto stageA = [&](auto xc, auto bufc, int kt) {
+  // the loaders walk the k-tiles themselves: A half 0, A half 1, next k-tile ...; B likewise
+  auto stageA = [&](auto xc, auto bufc) {
     constexpr int X = decltype(xc)::value, BUFI = decltype(bufc)::value;
-    const int k0 = kbeg + kt * BK;
-    if constexpr (X == 0) {   // A half 0 is staged before half 1 of the same k-tile
-      if (k0 < kend) la.enter_ktile(p, k0);
-    }
-    la.template issue<X>(p, lds0 + BUFI * C::BUF + (X ? OA1 : OA0), k0, kend, wave);
+    la.template issue<X>(p, lds0 + BUFI * C::BUF + (X ? OA1 : OA0), kend, wave);
   };
-  auto stageB = [&](auto yc, auto bufc, int kt) {
+  auto stageB = [&](auto yc, auto bufc) {
     constexpr int Y = decltype(yc)::value, BUFI = decltype(bufc)::value;
-    lb.template issue<Y>(p, lds0 + BUFI * C::BUF + (Y ? OB1 : OB0), lds0 + C::SCRATCH, kbeg + kt * BK, kend, wave);
+    lb.template issue<Y>(p, lds0 + BUFI * C::BUF + (Y ? OB1 : OB0), lds0 + C::SCRATCH, kend, wave);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
   // ---- prologue: k-tile 0 complete + the three half tiles of k-tile 1 the steady state has in flight at a k-tile's start ----
-  stageB(I0{}, I0{}, 0);
-  stageA(I0{}, I0{}, 0);
-  stageB(I1{}, I0{}, 0);
-  stageA(I1{}, I0{}, 0);
-  stageB(I0{}, I1{}, 1);
-  stageA(I0{}, I1{}, 1);
-  stageB(I1{}, I1{}, 1);
+  stageB(I0{}, I0{});
+  stageA(I0{}, I0{});
+  stageB(I1{}, I0{});
+  stageA(I1{}, I0{});
+  stageB(I0{}, I1{});
+  stageA(I0{}, I1{});
+  stageB(I1{}, I1{});
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
@@ -379,7 +404,7 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
   __builtin_amdgcn_s_barrier();
 
   // one k-tile = four phases; BUFI: the LDS buffer it is multiplied from, kt its index
-  auto ktile = [&](auto bufc, int kt) {
+  auto ktile = [&](auto bufc) {
     constexpr int BUFI = decltype(bufc)::value;
     using BX = std::integral_constant<int, BUFI>;
     using BY = std::integral_constant<int, BUFI ^ 1>;
@@ -389,31 +414,31 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
     __builtin_amdgcn_sched_barrier(0);
     readA(base + OA0);
     __builtin_amdgcn_sched_barrier(0);
-    stageA(I1{}, BY{}, kt + 1);
+    stageA(I1{}, BY{});
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT * 2) : "memory");   // the b0 reads (issued first) have returned: B half 0 may be restaged next phase
     G8_MFMA_PHASE(I0{}, I0{}, fb0)
     // phase 2: b1; DMA of B half 0 of k-tile kt+2 (this buffer)
     readB(base + OB1, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    stageB(I0{}, BX{}, kt + 2);
+    stageB(I0{}, BX{});
     G8_MFMA_PHASE(I0{}, I1{}, fb1)
     // phase 3: a1; DMA of A half 0 of k-tile kt+2
     readA(base + OA1);
     __builtin_amdgcn_sched_barrier(0);
-    stageA(I0{}, BX{}, kt + 2);
+    stageA(I0{}, BX{});
     G8_MFMA_PHASE(I1{}, I1{}, fb1)
     // phase 4: DMA of B half 1 of k-tile kt+2; everything older than the last three half tiles has landed = k-tile kt+1
-    stageB(I1{}, BX{}, kt + 2);
+    stageB(I1{}, BX{});
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     G8_MFMA_PHASE(I1{}, I0{}, fb0)
   };
 
   int kt = 0;
   for (; kt + 1 < nkt; kt += 2) {
-    ktile(I0{}, kt);
-    ktile(I1{}, kt + 1);
+    ktile(I0{});
+    ktile(I1{});
   }
-  if (kt < nkt) ktile(I0{}, kt);
+  if (kt < nkt) ktile(I0{});
 #undef G8_MFMA_PHASE
   if (grp == 0) __builtin_amdgcn_s_barrier();   // group 0 joins group 1's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile

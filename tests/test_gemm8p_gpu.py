@@ -113,7 +113,7 @@ def test_conv_gathers_exact(force_tile, tile, cfg):
 def test_conv_dgrad_fused_epilogues(force_tile, tile, cfg, nbn, with_res):
     force_tile(tile)
     T.test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res)
-    if tile != 4 and cfg[3] % 12 == 0:
+    if tile == 11 and cfg[3] % 12 == 0:      # (tile 0 = the shipped route: convolutions on the loader-wave kernels)
         assert "gemm8p_kernel" in _last_kernel(), _last_kernel()
 
 

@@ -10,6 +10,7 @@ int gemm_dma_dispatch_bn128(const HtrvtGemmDesc*, const KParams&, int, hipStream
 int gemm_dma_dispatch_bn128_s3(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_dma_dispatch_bn192(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_dma_dispatch_bn256(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
+int gemm_halo_try_launch(const HtrvtGemmDesc*, const KParams&, int bn, hipStream_t);
 }  // namespace htrvt
 
 namespace {
@@ -20,7 +21,7 @@ constexpr int BM_ = 256;
 // loader waves win 5-15 % on the conv forward/dgrad gathers and on K >= 2048 plain GEMMs, lose on MN-major A.
 bool use_loader_waves(const HtrvtGemmDesc* d) {
   if (d->tile == 3) return false;
-  if (d->tile == 4) return true;
+  if (d->tile == 4 || d->tile == 5 || d->tile == 12) return true;
   if (d->a_layout != HTRVT_KMAJOR) return false;
   return d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_DGRAD || d->K >= 2048;
 }
@@ -100,6 +101,10 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
       p.wq_shift = a;
       p.hwq_shift = b;
     }
+  }
+  if (bn == 192 || bn == 128) {   // 3x3 stride-1 convolutions whose M tiles are row segments: halo-staged A operand (gemm_halo_impl.h)
+    const int r = gemm_halo_try_launch(d, p, bn, st);
+    if (r != 0) return r;
   }
   const bool spec = use_loader_waves(d);
   if (bn == 256) return gemm_dma_dispatch_bn256(d, p, zdim, st, false);

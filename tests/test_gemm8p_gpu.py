@@ -150,3 +150,52 @@ def test_older_family_still_exact(force_tile):
         T.test_nt_plain_exact(BF, 512, 3072, 768)
         assert "gemm_dma_kernel" in _last_kernel()
         T.test_nt_epilogue(BF)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# halo-staged 3x3 stride-1 convolutions (csrc/gemm_halo_impl.h): forward (+ BatchNorm column sums) and dgrad against
+# torch's float64 convolution on integer data, at shapes that exercise every edge of the halo bookkeeping
+# --------------------------------------------------------------------------------------------------------------------
+HALO = [  # B, H, W, Ci, Co
+    (2, 4, 256, 192, 192),     # one tile per image row, 3 channel chunks, 192-column tile
+    (1, 1, 256, 64, 128),      # H = 1: both neighbour rows outside the image; 128-column tile
+    (3, 2, 512, 384, 384),     # two tiles per row (halo columns inside the image), two N tiles
+    (2, 3, 256, 96, 256),      # Ci = 96 -> Cpad 128: the last chunk is half padding; Co = 256 -> 128-column tiles
+    (1, 2, 768, 128, 64),      # three tiles per row, Co = 64: 64-column route (generic kernel) must still be right
+]
+
+
+@pytest.mark.parametrize("cfg", HALO)
+def test_halo_conv_forward_dgrad_exact(cfg):
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=50).requires_grad_(True)
+    w = T._ints((Co, Ci, 3, 3), -2, 3, seed=51)
+    y = F.conv2d(x, w, None, stride=1, padding=1)
+    dy = T._ints(tuple(y.shape), -2, 3, seed=52)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (1, 1), 1)
+    M = Bn * Hh * Ww
+    cpi, cpo = ops.cpad(Ci, BF), ops.cpad(Co, BF)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wf = T._pack_fwd(w, cpi).to(BF).cuda()
+    y_nhwc = y.detach().permute(0, 2, 3, 1)
+    outs = {}
+    for tile in (5, 12):         # 5: generic gather kernel, 12: halo kernel where eligible
+        yd = torch.full((Bn, Hh, Ww, Co), 9.0, dtype=BF, device="cuda")
+        nmt = ops.gemm_num_mtiles(M, Co, BF, gather=ops.GATHER_CONV_FWD)
+        cs = torch.zeros(nmt, 2, Co, dtype=torch.float32, device="cuda")
+        ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+                 Cpad=cpi, colstats=cs, tile=tile)
+        outs[tile] = _last_kernel()
+        assert torch.equal(yd.double().cpu(), y_nhwc.to(BF).double()), (tile, _last_kernel())
+        assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
+        assert torch.allclose(cs[:, 1].sum(0).double().cpu(), (y_nhwc.reshape(-1, Co) ** 2).sum(0), rtol=1e-6, atol=1e-3)
+        dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+        wd = T._pack_dgrad(w, cpo).to(BF).cuda()
+        dxd = torch.full((Bn, Hh, Ww, Ci), 9.0, dtype=BF, device="cuda")
+        ops.gemm(dyd, wd, dxd, dtype=BF, M=M, N=Ci, K=9 * cpo, lda=Co, ldb=9 * cpo, ldc=Ci, gather=ops.GATHER_CONV_DGRAD, geom=geom,
+                 Cpad=cpo, tile=tile)
+        assert torch.equal(dxd.double().cpu(), x.grad.permute(0, 2, 3, 1).to(BF).double()), (tile, _last_kernel())
+    if Ci >= 96:       # the dgrad's N = Ci: 192- or 128-column tiles -> the halo kernel must have run under tile 12
+        assert "gemm_halo_kernel" in outs[12] or "gemm_halo_kernel" in _last_kernel(), (outs, _last_kernel())

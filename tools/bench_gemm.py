@@ -186,6 +186,10 @@ def main():
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
         conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
         conv("l2.0 192->384 s2 [128,8,1024]", 128, 8, 1024, 192, 384, 3, (2, 2), 1)
+    if "s1conv" in args.only:      # the nine 3x3 stride-1 convolutions of the stem (three per stage), forward + dgrad + wgrad
+        conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
+        conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
+        conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
     for tag, ms, fl in rows:
         if isinstance(ms, dict):
             print(f"{tag:42s} " + "  ".join(f"{k}: {v:7.3f} ms {fl / v / 1e9:7.1f} TF" for k, v in ms.items()))

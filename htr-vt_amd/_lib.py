@@ -82,6 +82,8 @@ PROTOTYPES = {
     "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "htrvt_relpos_bias_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "htrvt_relpos_bias_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_cast_transpose_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_sumsq_blocks": (i32, [i64]),
     "htrvt_sumsq": (i32, [vp, i64, vp, vp, vp]),

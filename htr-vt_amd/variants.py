@@ -5,7 +5,9 @@
   tokens over the sequence rolled by `shift_size` (blocks 0 and 1 use windows of 16, shift 0 / 8).  Here: ONE dense
   additive bias [heads, N, N] -- table entries inside a window, a large negative number outside -- handed to the same
   fused attention kernels (bfloat16) or to the batched-GEMM + row-softmax path (float32); the gradient of the table is
-  the kernels' dense d(score) summed over the batch and gathered back along the diagonals.
+  the kernels' dense d(score) summed over the batch and gathered back per table entry.  The bias is built, and its
+  gradient gathered, by HIP kernels (csrc/variants.hip); a sequence that is not a multiple of the window (the
+  reference zero-pads it and masks the padding keys) or of the kernels' 128-token tiles is handled by masked columns.
 * model_sgm_* (/root/reference/model_sgm_2/model/sgm_head.py:118-127): the SGM head's single-head cross-attention
   softmax(Q K^T / sqrt(D)) K with K = V = the (normalised) visual tokens: batched htrvt_gemm + htrvt_softmax_rows over
   [B, L, D] queries and [B, N, D] tokens, forward and backward.
@@ -24,35 +26,60 @@ MASKED = -1.0e30      # "outside the window": finite, so an all-masked key tile 
 
 def relative_position_index(N, num_patches, window_size=0, shift_size=0):
     """(index [N, N] int64 into the bias table, inside [N, N] bool) for queries i / keys j of the ORIGINAL sequence.
-    Full attention (HTR_VT.py:27-31,45-46): index = (j - i) + P - 1.  Windowed (Block._attend, :113-154): token t sits at
-    position (t - shift) mod N of the rolled sequence, window = position // ws, slot = position % ws; a pair attends only
-    inside one window and uses the slots' distance."""
+    Full attention (HTR_VT.py:27-31,45-46): index = (j - i) + P - 1.  Windowed (Block._attend, :113-154): the sequence is
+    zero-padded to Np = a multiple of the window, token t sits at position (t - shift) mod Np of the rolled sequence,
+    window = position // ws, slot = position % ws; a pair attends only inside one window and uses the slots' distance.
+    The padding tokens are masked as keys (key_padding_mask, :47-56) and dropped as queries (:150-152), so among the N
+    real tokens they only move the window boundaries -- which Np in the modulus reproduces."""
     t = torch.arange(N)
     if window_size <= 0:
         return (t[None, :] - t[:, None]) + num_patches - 1, torch.ones(N, N, dtype=torch.bool)
-    if N % window_size:
-        raise ValueError(f"windowed attention: N={N} must be a multiple of window_size={window_size} (the reference pads and masks)")
-    pos = (t - shift_size) % N
+    Np = (N + window_size - 1) // window_size * window_size
+    pos = (t - shift_size) % Np
     win, slot = pos // window_size, pos % window_size
     return (slot[None, :] - slot[:, None]) + num_patches - 1, win[None, :] == win[:, None]
 
 
-def relative_position_bias(table, N, num_patches, window_size=0, shift_size=0):
-    """dense float32 [heads, N, N] score bias from the learned table [(2 P - 1), heads]"""
-    idx, inside = relative_position_index(N, num_patches, window_size, shift_size)
-    idx, inside = idx.to(table.device), inside.to(table.device)
-    bias = table.float()[idx].permute(2, 0, 1).contiguous()          # [h, N, N] (HTR_VT.py:45-46)
-    return torch.where(inside[None], bias, torch.full_like(bias, MASKED)).contiguous()
+def _padded_len(N, dtype, hd):
+    """sequence length the attention kernels run at: a multiple of 128 where the fused bfloat16 kernels can serve it (the
+    padding keys carry the bias -1e30, the padding queries are dropped), else a multiple of 8 (16-byte rows of the GEMMs)"""
+    from ._lib import lib as _l
+    n128 = (N + 127) // 128 * 128
+    if dtype == torch.bfloat16 and _l.htrvt_attn_supported(n128, hd, dt(dtype)):
+        return n128
+    return (N + 7) // 8 * 8
 
 
-def relative_position_bias_grad(dbias, table_shape, N, num_patches, window_size=0, shift_size=0):
-    """d(loss)/d(table) from the dense d(loss)/d(bias) [heads, N, N]: sum over the pairs that share a table entry"""
-    idx, inside = relative_position_index(N, num_patches, window_size, shift_size)
-    idx, inside = idx.to(dbias.device), inside.to(dbias.device)
-    g = torch.zeros(table_shape, dtype=torch.float32, device=dbias.device)
-    contrib = torch.where(inside[None], dbias, torch.zeros_like(dbias)).permute(1, 2, 0).reshape(-1, dbias.shape[0])
-    g.index_add_(0, idx.reshape(-1), contrib)
-    return g
+class _RelPosBias(torch.autograd.Function):
+    """table [(2P-1), heads] float32 (device) -> dense bias [heads, ld, ld]; both directions are HIP kernels
+    (csrc/variants.hip): lookup + window mask forward, per-entry gather-sum backward (no atomics)"""
+
+    @staticmethod
+    def forward(ctx, table, N, num_patches, window_size, shift_size, ld):
+        table = table.contiguous().float()
+        heads = table.shape[1]
+        bias = torch.empty(heads, ld, ld, dtype=torch.float32, device=table.device)
+        check(lib.htrvt_relpos_bias_fwd(ptr(table), ptr(bias), N, num_patches, window_size, shift_size, heads, ld, stream()),
+              "relpos_bias_fwd")
+        ctx.geo = (N, num_patches, window_size, shift_size, heads, ld, tuple(table.shape))
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        N, P, ws, shift, heads, ld, tshape = ctx.geo
+        dbias = dbias.contiguous().float()
+        dtable = torch.empty(tshape, dtype=torch.float32, device=dbias.device)
+        check(lib.htrvt_relpos_bias_bwd(ptr(dbias), ptr(dtable), N, P, ws, shift, heads, ld, stream()), "relpos_bias_bwd")
+        return dtable, None, None, None, None, None
+
+
+def relative_position_bias(table, N, num_patches, window_size=0, shift_size=0, ld=None):
+    """dense float32 [heads, ld, ld] score bias from the learned table [(2 P - 1), heads] (ld >= N: the sequence length the
+    attention kernels run at, see biased_self_attention; default N).  Differentiable in the table."""
+    if not table.is_cuda:
+        raise RuntimeError("htrvt_amd.variants needs device tensors on an MI355X (no CPU fallback); the index bookkeeping "
+                           "alone is relative_position_index()")
+    return _RelPosBias.apply(table, N, num_patches, window_size, shift_size, N if ld is None else ld)
 
 
 class _BiasedSelfAttention(torch.autograd.Function):
@@ -116,12 +143,34 @@ class _BiasedSelfAttention(torch.autograd.Function):
 
 
 def biased_self_attention(qkv, bias, B, N, heads):
-    """softmax(q k^T * hd^-0.5 + bias) v over qkv [B*N, 3*heads*hd] (layout [B,N,3,heads,hd]); bias [heads, N, N] float32
-    (see relative_position_bias).  bfloat16 with N % 128 == 0 and hd in {32, 64, 128}: the fused kernels; otherwise
-    (float32 parity path) batched GEMMs + row softmax.  Differentiable in qkv and bias."""
+    """softmax(q k^T * hd^-0.5 + bias) v over qkv [B*N, 3*heads*hd] (layout [B,N,3,heads,hd]); bias [heads, ld, ld] float32
+    with ld >= N (see relative_position_bias; columns >= N must hold -1e30).  bfloat16 with hd in {32, 64, 128}: the fused
+    kernels, the sequence zero-padded to a multiple of 128 if it is not one (masked keys, dropped queries); otherwise
+    (float32 parity path) batched GEMMs + row softmax at a multiple of 8.  Differentiable in qkv and bias."""
     if not qkv.is_cuda:
         raise RuntimeError("htrvt_amd.variants needs device tensors on an MI355X (no CPU fallback)")
-    return _BiasedSelfAttention.apply(qkv, bias, B, N, heads)
+    D3 = qkv.shape[1]
+    hd = D3 // 3 // heads
+    Np = _padded_len(N, qkv.dtype, hd)
+    ld = bias.shape[-1]
+    if ld != Np:
+        if ld != N:
+            raise ValueError(f"bias is [{heads}, {ld}, {ld}]: expected ld = {N} or the padded length {Np}")
+        padded = torch.full((heads, Np, Np), MASKED, dtype=torch.float32, device=bias.device)
+        padded[:, :N, :N] = bias            # (glue: a strided copy; use relative_position_bias(..., ld=padded_len) to avoid it)
+        padded[:, N:, 0] = 0.0
+        bias = padded
+    if Np == N:
+        return _BiasedSelfAttention.apply(qkv, bias, B, N, heads)
+    qp = torch.zeros(B, Np, D3, dtype=qkv.dtype, device=qkv.device)
+    qp[:, :N] = qkv.view(B, N, D3)
+    out = _BiasedSelfAttention.apply(qp.view(B * Np, D3), bias, B, Np, heads)
+    return out.view(B, Np, -1)[:, :N].reshape(B * N, -1)
+
+
+def padded_len(N, dtype, head_dim):
+    """the `ld` to build the bias at for biased_self_attention"""
+    return _padded_len(N, dtype, head_dim)
 
 
 class _CrossAttention(torch.autograd.Function):

@@ -232,6 +232,17 @@ int htrvt_conv1_bwd(const void* img, const float* stats, const void* dpool, cons
                     const float* gamma, const float* mean, const float* rstd, float* partial, float* dw, float* dgamma,
                     float* dbeta, int B, int H, int W, int C, int dtype, int img_u8, void* stream);
 
+/* ---- variant blocks: relative-position bias of the window-attention fork -------------------------
+ * model_window/model/HTR_VT.py:23-31,45-46 (table [(2P-1)][heads] + index) and :113-154 (Block._attend: pad to a multiple
+ * of the window, cyclic shift, 1-D windows, key_padding_mask) as one dense additive score bias [heads][ld][ld] for
+ * htrvt_attn_fwd / htrvt_softmax_rows: table entry inside a window, -1e30 outside and in the columns N..ld-1 (sequence
+ * padded for the kernels; rows N..ld-1 are don't-care queries).  window <= 0: full attention.
+ * _bwd: dtable[(2P-1)][heads] = gather-sum of dbias over the (query, key) pairs of each entry, fixed order, overwrites. */
+int htrvt_relpos_bias_fwd(const float* table, float* bias, int N, int num_patches, int window, int shift, int heads, int ld,
+                          void* stream);
+int htrvt_relpos_bias_bwd(const float* dbias, float* dtable, int N, int num_patches, int window, int shift, int heads, int ld,
+                          void* stream);
+
 /* ---- weight layout helpers ----------------------------------------------------- */
 /* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */
 int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,

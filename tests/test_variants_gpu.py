@@ -54,7 +54,7 @@ def test_window_relative_bias_attention_forward_backward(dtype, ws, shift):
 
     qd = qkv.cuda().requires_grad_(True)
     td = table.cuda().requires_grad_(True)
-    bias = V.relative_position_bias(td, N, P, ws, shift)
+    bias = V.relative_position_bias(td, N, P, ws, shift)          # HIP kernel (csrc/variants.hip), differentiable in the table
     out = V.biased_self_attention(qd, bias, B, N, h)
     out.backward(dout.cuda())
     f32 = dtype == torch.float32
@@ -97,3 +97,73 @@ def test_sgm_cross_attention_forward_backward(dtype, L, N, D):
         cos = float((got.flatten() @ want.flatten()) / (got.norm() * want.norm()))
         print(f"{dtype} L={L} N={N} D={D} {name}: rel-to-max {e:.3e} cosine {cos:.6f}")
         assert e < (1e-4 if f32 else 3e-2) and cos > (0.999999 if f32 else 0.999), (name, e, cos)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# pinned by the reference: tools/make_goldens_variants.py ran model_window's Block._attend / Attention.forward and
+# model_sgm_2's SGMHead._cross_attend (float64, CPU) on the seeded inputs of tests/variant_cases.py
+# --------------------------------------------------------------------------------------------------------------------
+import os          # noqa: E402
+
+import numpy as np     # noqa: E402
+
+import variant_cases as VC    # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", VC.WINDOW_CASES, ids=lambda c: c[0])
+def test_window_attention_against_reference_fixture(golden_dir, dtype, case):
+    """x -> qkv Linear -> [relative bias (+ windows, shift, padding) attention: the kernels] -> proj, forward and the
+    gradients of x, the bias table and the qkv bias, against the reference module's own output.  The two Linears around
+    the kernels are torch glue here (the model's Linears are htrvt_gemm; tests/test_model_gpu.py covers those)."""
+    from htrvt_amd import variants as V
+    tag, B, N, dim, heads, P, ws, shift = case
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    inp = {k: torch.from_numpy(v).float().cuda() for k, v in VC.window_inputs(case).items()}
+    x = inp["x"].clone().requires_grad_(True)
+    table = inp["table"].clone().requires_grad_(True)
+    qb = inp["qkv_b"].clone().requires_grad_(True)
+    hd = dim // heads
+    qkv = (x.reshape(B * N, dim) @ inp["qkv_w"].t() + qb).to(dtype)
+    ld = V.padded_len(N, dtype, hd)
+    bias = V.relative_position_bias(table, N, P, ws, shift, ld=ld)
+    core = V.biased_self_attention(qkv, bias, B, N, heads)
+    y = core.float() @ inp["proj_w"].t() + inp["proj_b"]
+    y.backward(inp["gout"].reshape(B * N, dim))
+    f32 = dtype == torch.float32
+    want = torch.from_numpy(g[f"win.{tag}.y"]).reshape(B * N, dim)
+    err = (y.detach().cpu() - want).abs().max().item() / want.abs().max().item()
+    print(f"{tag} {dtype}: ld {ld}, y rel-to-max {err:.3e}")
+    assert err < (2e-5 if f32 else 2e-2), err
+    for name, got in (("dx", x.grad.reshape(B, N, dim)), ("dtable", table.grad), ("dqkv_b", qb.grad)):
+        w_ = torch.from_numpy(g[f"win.{tag}.{name}"])
+        got = got.cpu()
+        e = (got - w_).abs().max().item() / w_.abs().max().item()
+        cos = float((got.flatten().double() @ w_.flatten().double()) / (got.double().norm() * w_.double().norm()))
+        print(f"   {name}: rel-to-max {e:.3e} cosine {cos:.6f}")
+        assert e < (1e-4 if f32 else 4e-2) and cos > (0.999999 if f32 else 0.999), (name, e, cos)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", VC.SGM_CASES, ids=lambda c: c[0])
+def test_sgm_cross_attention_against_reference_fixture(golden_dir, dtype, case):
+    """kv LayerNorm (htrvt_layernorm_fwd/bwd are the model's; torch glue here) -> cross-attention kernels, vs SGMHead._cross_attend"""
+    from htrvt_amd import variants as V
+    tag, B, L, N, D = case
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    inp = {k: torch.from_numpy(v).float().cuda() for k, v in VC.sgm_inputs(case).items()}
+    Q = inp["Q"].clone().requires_grad_(True)
+    Fv = inp["F"].clone().requires_grad_(True)
+    K = torch.nn.functional.layer_norm(Fv, (D,), inp["ln_w"], inp["ln_b"], 1e-5)
+    y = V.cross_attention(Q.to(dtype), K.to(dtype)).float()
+    y.backward(inp["gout"])
+    f32 = dtype == torch.float32
+    want = torch.from_numpy(g[f"sgm.{tag}.y"])
+    assert (y.detach().cpu() - want).abs().max().item() < (3e-5 if f32 else 3e-2) * want.abs().max().item()
+    for name, got in (("dQ", Q.grad), ("dF", Fv.grad)):
+        w_ = torch.from_numpy(g[f"sgm.{tag}.{name}"])
+        got = got.cpu()
+        e = (got - w_).abs().max().item() / w_.abs().max().item()
+        cos = float((got.flatten().double() @ w_.flatten().double()) / (got.double().norm() * w_.double().norm()))
+        print(f"{tag} {dtype} {name}: rel-to-max {e:.3e} cosine {cos:.6f}")
+        assert e < (2e-4 if f32 else 4e-2) and cos > (0.99999 if f32 else 0.999), (name, e, cos)

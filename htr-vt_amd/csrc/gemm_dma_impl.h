@@ -748,6 +748,93 @@ __device__ __forceinline__ void gemm_dma_body(const P& p, const int block_x) {
 
   int a_cur = 0, a_nxt = AST - 1;   // A buffer being multiplied / A buffer the DMA issued in this iteration fills
   int b_cur = 0, b_nxt = BST - 1;
+  // STAGGER (every wave loads AND multiplies, two LDS stages: the weight-gradient products): with all eight waves in
+  // lockstep behind the k-tile's barrier they all issue their DMA pieces first -- ~700 cycles in which no wave has an
+  // MFMA in the pipe -- and then all multiply.  Ablation on the layer-1 conv weight gradient: MFMA side alone 0.52 ms, DMA
+  // alone 0.57 ms, together 0.80 ms.  Waves 4-7 (the SIMD partners of waves 0-3) therefore run HALF A K-TILE BEHIND: they
+  // read the fragments of a k-tile's last two k-steps into registers before the barrier and multiply them after it,
+  // while waves 0-3 issue their DMA; then they issue theirs while waves 0-3 multiply.  (MI355X_MICROARCH.md, Two waves per
+  // SIMD, item 9: split by wave number >= 4.)
+#ifdef HTRVT_EXP_NOSTAGGER
+  constexpr bool STAGGER = false;
+#else
+  constexpr bool STAGGER = SPEC == 0 && NSTAGE == 2 && AL == HTRVT_MNMAJOR;
+#endif
+  const bool late = STAGGER && wave >= NWC / 2;
+  auto advance = [&]() {
+    a_cur = (a_cur + 1 == AST) ? 0 : a_cur + 1;
+    a_nxt = (a_nxt + 1 == AST) ? 0 : a_nxt + 1;
+    b_cur = (b_cur + 1 == BST) ? 0 : b_cur + 1;
+    b_nxt = (b_nxt + 1 == BST) ? 0 : b_nxt + 1;
+  };
+  if (late) {
+    // ---- waves 4-7 of a staggered kernel: one barrier per iteration, like the loop below ----
+    bf16x8_t ha0[TM], ha1[TM], hb0[TN], hb1[TN];      // fragments of k-steps 2 and 3 of the previous k-tile
+    for (int kt = 0; kt < nkt; ++kt) {
+      const char* sa = smem + a_cur * A_BYTES;
+      const char* sb = smem + B_BASE + b_cur * B_BYTES;
+#ifndef HTRVT_EXP_NOMMA
+      if (kt > 0) {          // k-steps 2, 3 of k-tile kt-1, from registers: runs beside the early waves' DMA issue
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0[i], hb0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha1[i], hb1[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef HTRVT_EXP_NODMA
+      if (kt + 1 < nkt) {
+        lb.template issue<KMAP>(p, lds0 + B_BASE + b_nxt * B_BYTES, kbeg + (kt + 1) * BK, kend, lw);
+        la.issue(p, lds0 + a_nxt * A_BYTES, kbeg + (kt + 1) * BK, kend, lw);
+      }
+#endif
+#ifndef HTRVT_EXP_NOMMA
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ha0[i] = frag_read<BM, AL>(sa, wm * TM + i, 2, lane);
+        ha1[i] = frag_read<BM, AL>(sa, wm * TM + i, 3, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        hb0[j] = frag_read<BN, BL>(sb, wn * TN + j, 2, lane);
+        hb1[j] = frag_read<BN, BL>(sb, wn * TN + j, 3, lane);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the held fragments are in registers before this stage is refilled
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      advance();
+    }
+#ifndef HTRVT_EXP_NOMMA
+    if (nkt > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0[i], hb0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha1[i], hb1[j], acc[i][j], 0, 0, 0);
+    }
+#endif
+  } else {
   for (int kt = 0; kt < nkt; ++kt) {
     const char* sa = smem + a_cur * A_BYTES;
     const char* sb = smem + B_BASE + b_cur * B_BYTES;
@@ -785,10 +872,8 @@ __device__ __forceinline__ void gemm_dma_body(const P& p, const int block_x) {
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    a_cur = (a_cur + 1 == AST) ? 0 : a_cur + 1;
-    a_nxt = (a_nxt + 1 == AST) ? 0 : a_nxt + 1;
-    b_cur = (b_cur + 1 == BST) ? 0 : b_cur + 1;
-    b_nxt = (b_nxt + 1 == BST) ? 0 : b_nxt + 1;
+    advance();
+  }
   }
 
   HTRVT_STAMP(3);

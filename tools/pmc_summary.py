@@ -72,7 +72,7 @@ def main():
     gmf, _ = load(os.path.join(a.src, "mfma"), by_grid=True)
     grows = []
     for key in gfe:
-        if not key[0].startswith(("gemm_", "attn_")):
+        if not key[0].startswith(("gemm", "attn_")):
             continue
         fs, ws = gfe[key].get("FETCH_SIZE", []), gwr.get(key, {}).get("WRITE_SIZE", [])
         busy, gui = sum(gmf.get(key, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", [])), sum(gmf.get(key, {}).get("GRBM_GUI_ACTIVE", []))

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="training steps the profiled command executed")
     ap.add_argument("--title", default="")
     ap.add_argument("--cmd", default="")
-    ap.add_argument("--by-grid", default="gemm_,attn_", help="comma-separated symbol prefixes listed per launch grid as well")
+    ap.add_argument("--by-grid", default="gemm,attn_", help="comma-separated symbol prefixes listed per launch grid as well")
     a = ap.parse_args()
     f = glob.glob(os.path.join(a.src, "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(f)))

@@ -142,15 +142,17 @@ struct TileStage {
     *reinterpret_cast<u32x4_t*>(tile + lds_off<HD>(row_of(u), ch_of(u))) = v;
   }
 
-  __device__ __forceinline__ void issue(const bf16_t* base, long long ld, int row0) {
-    r0 = ld16(base, ld, row0 + row_of(0), ch_of(0));
-    if constexpr (NL > 1) r1 = ld16(base, ld, row0 + row_of(1), ch_of(1));
-    if constexpr (NL > 2) r2 = ld16(base, ld, row0 + row_of(2), ch_of(2));
-    if constexpr (NL > 3) r3 = ld16(base, ld, row0 + row_of(3), ch_of(3));
-    if constexpr (NL > 4) r4 = ld16(base, ld, row0 + row_of(4), ch_of(4));
-    if constexpr (NL > 5) r5 = ld16(base, ld, row0 + row_of(5), ch_of(5));
-    if constexpr (NL > 6) r6 = ld16(base, ld, row0 + row_of(6), ch_of(6));
-    if constexpr (NL > 7) r7 = ld16(base, ld, row0 + row_of(7), ch_of(7));
+  // rows past `last` (the sequence's last token: a partial final tile) re-read that row -- always valid memory; whatever
+  // they contribute is masked by the caller (scores of padding keys -> -inf / probabilities of padding queries -> 0)
+  __device__ __forceinline__ void issue(const bf16_t* base, long long ld, int row0, int last) {
+    r0 = ld16(base, ld, min(row0 + row_of(0), last), ch_of(0));
+    if constexpr (NL > 1) r1 = ld16(base, ld, min(row0 + row_of(1), last), ch_of(1));
+    if constexpr (NL > 2) r2 = ld16(base, ld, min(row0 + row_of(2), last), ch_of(2));
+    if constexpr (NL > 3) r3 = ld16(base, ld, min(row0 + row_of(3), last), ch_of(3));
+    if constexpr (NL > 4) r4 = ld16(base, ld, min(row0 + row_of(4), last), ch_of(4));
+    if constexpr (NL > 5) r5 = ld16(base, ld, min(row0 + row_of(5), last), ch_of(5));
+    if constexpr (NL > 6) r6 = ld16(base, ld, min(row0 + row_of(6), last), ch_of(6));
+    if constexpr (NL > 7) r7 = ld16(base, ld, min(row0 + row_of(7), last), ch_of(7));
   }
   __device__ __forceinline__ void commit(char* tile) const {
     st16(tile, 0, r0);
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int ND = HD / 32;       // 32-row tiles of O^T
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
 
-  const int nqb = p.N / QB;
+  const int nqb = (p.N + QB - 1) / QB;
+  const int last = p.N - 1;
   const int total = gridDim.x;
   int id = blockIdx.x;
   if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);   // the query blocks of one head share an XCD (K/V in its L2)
@@ -214,16 +217,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   const int r = lane & 31, hf = lane >> 5;
   const LaneAddr<HD> la = lane_addr<HD>(lane);
   const int q0 = qb * QB + wave * 32;
+  const int qrow = min(q0 + r, last);      // a padding query of the last block re-reads the last token; its row is not stored
 
   // Q^T as the B operand of S^T = K Q^T: lane (r, hf) holds Q[q0 + r][16 s + 8 hf .. + 7]
   bf16x8_t qf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
-    qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)(q0 + r) * ld + 16 * s + 8 * hf));
+    qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)qrow * ld + 16 * s + 8 * hf));
 
   TileStage<HD, NTH> sk, sv;
-  sk.issue(kbase, ld, 0);
-  sv.issue(vbase, ld, 0);
+  sk.issue(kbase, ld, 0, last);
+  sv.issue(vbase, ld, 0, last);
   sk.commit(smem);
   sv.commit(smem + TILE_B);
   __syncthreads();
@@ -235,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m = -INFINITY, l = 0.f;     // running max (scaled base-2 domain) and this lane half's share of the running sum
 
-  const int nt = p.N / KT;
+  const int nt = (p.N + KT - 1) / KT;
+  const bool ragged = (p.N % KT) != 0;      // the last key tile holds padding keys
   for (int t = 0; t < nt; ++t) {
     const char* kt = smem + (t & 1) * 2 * TILE_B;
     const char* vt = kt + TILE_B;
@@ -244,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // loads, so the staging registers stay registers
     const int tn = min(t + 1, nt - 1);
     if constexpr (!(DBG & 1)) {
-      sk.issue(kbase, ld, tn * KT);
-      sv.issue(vbase, ld, tn * KT);
+      sk.issue(kbase, ld, tn * KT, last);
+      sv.issue(vbase, ld, tn * KT, last);
     }
     // S^T tiles: keys 32 c .. 32 c + 31 of this tile x the wave's 32 queries
     f32x16_t st[2];
@@ -256,6 +261,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kt, la, 32 * c, s), qf[s], st[c], 0, 0, 0);
+    }
+    if (!BIAS && ragged && t == nt - 1) {   // workgroup-uniform: scores of the padding keys -> -inf (probability 0)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) st[c][i] = -INFINITY;
     }
     // online softmax for query r: this lane holds 32 of the tile's 64 keys, lane ^ 32 the other 32
     if constexpr (!(DBG & 2)) {
@@ -321,8 +333,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
   l += xhalf(l);
   const float inv = 1.0f / l;
-  store_lane_rows<ND>(o, p.out + ((long long)b * p.N + q0 + r) * ((long long)p.h * HD) + hh * HD, hf, inv);
-  if (hf == 0 && p.lse2 != nullptr) p.lse2[(long long)bh * p.N + q0 + r] = m + log2f(l);
+  if (q0 + r <= last) {
+    store_lane_rows<ND>(o, p.out + ((long long)b * p.N + q0 + r) * ((long long)p.h * HD) + hh * HD, hf, inv);
+    if (hf == 0 && p.lse2 != nullptr) p.lse2[(long long)bh * p.N + q0 + r] = m + log2f(l);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -337,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
   constexpr int NS = HD / 16, ND = HD / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
 
-  const int nqb = p.N / QB;
+  const int nqb = (p.N + QB - 1) / QB;
+  const int last = p.N - 1;
   const int total = gridDim.x;
   int id = blockIdx.x;
   if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
@@ -355,12 +370,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
 
   bf16x8_t qf[NS], dof[NS];
   float dl = 0.f;
+  const int qrow = min(q0 + r, last);
   {
-    const bf16_t* dorow = p.dout + ((long long)b * p.N + q0 + r) * ldo + hh * HD;
-    const bf16_t* orow = p.o + ((long long)b * p.N + q0 + r) * ldo + hh * HD;
+    const bf16_t* dorow = p.dout + ((long long)b * p.N + qrow) * ldo + hh * HD;
+    const bf16_t* orow = p.o + ((long long)b * p.N + qrow) * ldo + hh * HD;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)(q0 + r) * ld + 16 * s + 8 * hf));
+      qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qbase + (long long)qrow * ld + 16 * s + 8 * hf));
       Vec16<bf16_t> vd, vo;
       vd.raw = *reinterpret_cast<const uint4*>(dorow + 16 * s + 8 * hf);
       vo.raw = *reinterpret_cast<const uint4*>(orow + 16 * s + 8 * hf);
@@ -370,12 +386,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
     }
   }
   dl += xhalf(dl);                                    // delta[q] = sum_d dO[q][d] O[q][d]
-  const float lse = p.lse2[(long long)bh * p.N + q0 + r];
-  if (hf == 0) delta[(long long)bh * p.N + q0 + r] = dl;
+  const float lse = p.lse2[(long long)bh * p.N + qrow];
+  if (hf == 0 && q0 + r <= last) delta[(long long)bh * p.N + q0 + r] = dl;
 
   TileStage<HD, NTH> sk, sv;
-  sk.issue(kbase, ld, 0);
-  sv.issue(vbase, ld, 0);
+  sk.issue(kbase, ld, 0, last);
+  sv.issue(vbase, ld, 0, last);
   sk.commit(smem);
   sv.commit(smem + TILE_B);
   __syncthreads();
@@ -386,14 +402,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
 
-  const int nt = p.N / KT;
+  const int nt = (p.N + KT - 1) / KT;
+  const bool ragged = (p.N % KT) != 0;
   for (int t = 0; t < nt; ++t) {
     const char* kt = smem + (t & 1) * 2 * TILE_B;
     const char* vt = kt + TILE_B;
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE_B;
     const int tn = min(t + 1, nt - 1);
-    sk.issue(kbase, ld, tn * KT);
-    sv.issue(vbase, ld, tn * KT);
+    sk.issue(kbase, ld, tn * KT, last);
+    sv.issue(vbase, ld, tn * KT, last);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       f32x16_t st, dp;
@@ -416,9 +433,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
           }
         }
       } else {
+        const bool mask = ragged && t == nt - 1;        // workgroup-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
+          float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
+          if (mask && t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) pr = 0.f;     // padding key
           st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
         }
       }
@@ -434,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
     sv.commit(nxt + TILE_B);
     __syncthreads();
   }
-  store_lane_rows<ND>(dq, p.dqkv + ((long long)b * p.N + q0 + r) * ld + hh * HD, hf, 1.0f);
+  if (q0 + r <= last) store_lane_rows<ND>(dq, p.dqkv + ((long long)b * p.N + q0 + r) * ld + hh * HD, hf, 1.0f);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -454,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
   constexpr int NS = HD / 16, ND = HD / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int nkb = p.N / KB;
+  const int nkb = (p.N + KB - 1) / KB;
+  const int last = p.N - 1;
   const int total = gridDim.x;
   int id = blockIdx.x;
   if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
@@ -476,8 +496,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
   bf16x8_t kf[NS], vf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    kf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
-    vf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vbase + (long long)(k0 + r) * ld + 16 * s + 8 * hf));
+    kf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kbase + (long long)min(k0 + r, last) * ld + 16 * s + 8 * hf));
+    vf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vbase + (long long)min(k0 + r, last) * ld + 16 * s + 8 * hf));
   }
 
   TileStage<HD, NTH, QT> sq, sd;
@@ -485,10 +505,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
   // re-read entry 0: no branch around the load)
   const float* cbase = threadIdx.x < QT ? lsebase + threadIdx.x : (threadIdx.x < 2 * QT ? delbase + (threadIdx.x - QT) : lsebase);
   const int cslot = threadIdx.x < 2 * QT ? threadIdx.x : 2 * QT;       // slot 2*QT: a dump word behind the two arrays
+  const int cidx = threadIdx.x < QT ? (int)threadIdx.x : (threadIdx.x < 2 * QT ? (int)threadIdx.x - QT : 0);   // query of the tile this thread's constant belongs to
   float sc;
-  sq.issue(qbase, ld, 0);
-  sd.issue(dobase, ldo, 0);
-  sc = cbase[0];
+  sq.issue(qbase, ld, 0, last);
+  sd.issue(dobase, ldo, 0, last);
+  sc = cbase[min(cidx, last) - cidx];
   sq.commit(smem);
   sd.commit(smem + TILE_B);
   reinterpret_cast<float*>(smem + 2 * TILE_B)[cslot] = sc;
@@ -500,16 +521,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
     for (int i = 0; i < 16; ++i) dk[d][i] = dv[d][i] = 0.f;
 
-  const int nt = p.N / QT;
+  const int nt = (p.N + QT - 1) / QT;
+  const bool ragged = (p.N % QT) != 0;      // the last query tile holds padding queries
   for (int t = 0; t < nt; ++t) {
     const char* qt = smem + (t & 1) * STAGE_B;
     const char* dot = qt + TILE_B;
     const float* cst = reinterpret_cast<const float*>(qt + 2 * TILE_B);
     char* nxt = smem + ((t + 1) & 1) * STAGE_B;
     const int tn = min(t + 1, nt - 1);
-    sq.issue(qbase, ld, tn * QT);
-    sd.issue(dobase, ldo, tn * QT);
-    sc = cbase[tn * QT];
+    sq.issue(qbase, ld, tn * QT, last);
+    sd.issue(dobase, ldo, tn * QT, last);
+    sc = cbase[min(tn * QT + cidx, last) - cidx];
 #pragma unroll
     for (int c = 0; c < QT / 32; ++c) {
       f32x16_t st, dp;
@@ -534,11 +556,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
             boff = ((long long)hh * p.N + t * QT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
             sb = fmaf(p.bias[boff], LOG2E, sb);
           }
-          const float pr = fast_exp2(fmaf(st[i], p.sl2, sb));
+          float pr = fast_exp2(fmaf(st[i], p.sl2, sb));
+          if (!BIAS && ragged && t == nt - 1 && t * QT + 32 * c + 8 * g + 4 * hf + j > last) pr = 0.f;   // padding query
           const float dsu = pr * (dp[i] - dev[j]);                          // d(score): gradient of the bias entry too
-          if constexpr (BIAS) {   // summed over the batch
+          if constexpr (BIAS) {   // summed over the batch (skipped when the bias is a constant mask: dbias == NULL)
             typedef __attribute__((address_space(1))) float gfloat;
-            __hip_atomic_fetch_add((gfloat*)(p.dbias + boff), dsu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.dbias != nullptr) __hip_atomic_fetch_add((gfloat*)(p.dbias + boff), dsu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           st[i] = pr;                                                       // P
           dp[i] = dsu * p.scale;                                            // dS
@@ -559,9 +582,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
     reinterpret_cast<float*>(nxt + 2 * TILE_B)[cslot] = sc;
     __syncthreads();
   }
-  bf16_t* grow = p.dqkv + ((long long)b * p.N + k0 + r) * ld + hh * HD;
-  store_lane_rows<ND>(dk, grow + p.h * HD, hf, 1.0f);
-  store_lane_rows<ND>(dv, grow + 2 * p.h * HD, hf, 1.0f);
+  if (k0 + r <= last) {
+    bf16_t* grow = p.dqkv + ((long long)b * p.N + k0 + r) * ld + hh * HD;
+    store_lane_rows<ND>(dk, grow + p.h * HD, hf, 1.0f);
+    store_lane_rows<ND>(dv, grow + 2 * p.h * HD, hf, 1.0f);
+  }
 }
 
 template <typename K>
@@ -583,7 +608,7 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
     if (int rc = set_lds(kern, smem, "attn_fwd")) return rc;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.B * p.h * (p.N / 128)), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.h * ((p.N + 127) / 128)), dim3(256), smem, st, p);
   return check_launch("attn_fwd");
 }
 
@@ -600,7 +625,7 @@ int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
     if (int rc = set_lds(kkv, smem_kv, "attn_bwd_dkv")) return rc;
     attr_done = true;
   }
-  const dim3 grid(p.B * p.h * (p.N / 128));
+  const dim3 grid(p.B * p.h * ((p.N + 127) / 128));
   hipLaunchKernelGGL(kq, grid, dim3(256), smem_dq, st, p, delta);
   hipLaunchKernelGGL(kkv, grid, dim3(256), smem_kv, st, p, (const float*)delta);
   return check_launch("attn_bwd");
@@ -608,15 +633,18 @@ int launch_bwd(const AttnParams& p, float* delta, hipStream_t st) {
 
 }  // namespace
 
+// any sequence length >= 32 (a partial last tile is masked in the kernels); with a score bias: multiples of 128 only
+// (the bias rows are read in whole tiles)
 extern "C" int htrvt_attn_supported(int N, int hd, int dtype) {
-  return dtype == HTRVT_BF16 && N >= 128 && N % 128 == 0 && (hd == 32 || hd == 64 || hd == 128);
+  return dtype == HTRVT_BF16 && N >= 32 && (hd == 32 || hd == 64 || hd == 128);
 }
 
 extern "C" int htrvt_attn_fwd(const void* qkv, const float* bias, void* out, float* lse2, int B, int N, int heads, int hd,
                               float scale, int dtype, void* stream) {
   HTRVT_REQUIRE(qkv && out, "htrvt_attn_fwd: null operand");
   HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
-                "htrvt_attn_fwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
+                "htrvt_attn_fwd: unsupported shape/dtype (N=%d >= 32, hd=%d in {32,64,128}, bfloat16)", N, hd);
+  HTRVT_REQUIRE(bias == nullptr || N % 128 == 0, "htrvt_attn_fwd: with a score bias N=%d must be a multiple of 128 (pad, masking the padding keys in the bias)", N);
   HTRVT_REQUIRE((long long)B * N * 3 * heads * hd < (1ll << 31), "htrvt_attn_fwd: qkv too large");
   AttnParams p{};
   p.qkv = (const bf16_t*)qkv;
@@ -642,7 +670,8 @@ extern "C" int htrvt_attn_bwd(const void* qkv, const float* bias, const void* ou
                               void* stream) {
   HTRVT_REQUIRE(qkv && out && dout && lse2 && delta && dqkv, "htrvt_attn_bwd: null operand");
   HTRVT_REQUIRE(B > 0 && heads > 0 && htrvt_attn_supported(N, hd, dtype),
-                "htrvt_attn_bwd: unsupported shape/dtype (N=%d must be a multiple of 128, hd=%d in {32,64,128}, bfloat16)", N, hd);
+                "htrvt_attn_bwd: unsupported shape/dtype (N=%d >= 32, hd=%d in {32,64,128}, bfloat16)", N, hd);
+  HTRVT_REQUIRE(bias == nullptr || N % 128 == 0, "htrvt_attn_bwd: with a score bias N=%d must be a multiple of 128", N);
   AttnParams p{};
   p.qkv = (const bf16_t*)qkv;
   p.o = (const bf16_t*)out;
@@ -654,7 +683,7 @@ extern "C" int htrvt_attn_bwd(const void* qkv, const float* bias, const void* ou
   p.B = B; p.N = N; p.h = heads;
   p.scale = scale;
   p.sl2 = scale * LOG2E;
-  HTRVT_REQUIRE((dbias != nullptr) == (bias != nullptr), "htrvt_attn_bwd: bias and dbias go together (both or neither)");
+  HTRVT_REQUIRE(dbias == nullptr || bias != nullptr, "htrvt_attn_bwd: dbias without a bias");   // bias without dbias: a constant mask
   hipStream_t st = (hipStream_t)stream;
   if (bias != nullptr) {
     if (hd == 128) return launch_bwd<128, true>(p, delta, st);

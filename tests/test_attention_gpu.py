@@ -13,7 +13,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 256, 6, 128), (3, 128, 6, 128), (1, 512, 6, 128), (2, 256, 8, 64), (2, 128, 4, 64), (4, 128, 2, 32)]
+SHAPES = [(2, 256, 6, 128), (3, 128, 6, 128), (1, 512, 6, 128), (2, 256, 8, 64), (2, 128, 4, 64), (4, 128, 2, 32),
+          # sequence lengths that are not multiples of the 128-query / 64-key tiles (W = 576 -> N = 144, ...): partial
+          # last tiles, masked padding keys / queries (reference: HTR_VT.py:27-39 has no length restriction)
+          (2, 144, 6, 128), (3, 200, 4, 64), (2, 72, 2, 32), (1, 328, 6, 128), (2, 40, 2, 64)]
 
 
 def _lib():
@@ -59,8 +62,8 @@ def test_supported_predicate():
     lib, _, _, _ = _lib()
     assert lib.htrvt_attn_supported(256, 128, 1) and lib.htrvt_attn_supported(128, 32, 1) and lib.htrvt_attn_supported(512, 64, 1)
     assert not lib.htrvt_attn_supported(256, 128, 0)      # float32 parity path: batched GEMMs + row softmax
-    assert not lib.htrvt_attn_supported(64, 128, 1) and not lib.htrvt_attn_supported(192, 64, 1)
-    assert not lib.htrvt_attn_supported(256, 96, 1)
+    assert lib.htrvt_attn_supported(64, 128, 1) and lib.htrvt_attn_supported(192, 64, 1) and lib.htrvt_attn_supported(144, 128, 1)
+    assert not lib.htrvt_attn_supported(256, 96, 1) and not lib.htrvt_attn_supported(16, 64, 1)
 
 
 @pytest.mark.parametrize("B,N,h,hd", SHAPES)

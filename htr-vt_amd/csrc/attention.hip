@@ -432,12 +432,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
             st[4 * g + j] = pr * (dp[4 * g + j] - dl) * p.scale;
           }
         }
-      } else {
-        const bool mask = ragged && t == nt - 1;        // workgroup-uniform
+      } else if (ragged && t == nt - 1) {               // workgroup-uniform: the tile with the padding keys
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
-          if (mask && t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) pr = 0.f;     // padding key
+          if (t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) pr = 0.f;
+          st[i] = pr * (dp[i] - dl) * p.scale;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
           st[i] = pr * (dp[i] - dl) * p.scale;          // dS^T
         }
       }
@@ -509,7 +514,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
   float sc;
   sq.issue(qbase, ld, 0, last);
   sd.issue(dobase, ldo, 0, last);
+  const bool is_lse = threadIdx.x < QT;
   sc = cbase[min(cidx, last) - cidx];
+  if (is_lse && cidx > last) sc = INFINITY;       // padding query of a partial tile: exp2(s - inf) = 0, no NaN (s is finite)
   sq.commit(smem);
   sd.commit(smem + TILE_B);
   reinterpret_cast<float*>(smem + 2 * TILE_B)[cslot] = sc;
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
     sq.issue(qbase, ld, tn * QT, last);
     sd.issue(dobase, ldo, tn * QT, last);
     sc = cbase[min(tn * QT + cidx, last) - cidx];
+    if (is_lse && tn * QT + cidx > last) sc = INFINITY;
 #pragma unroll
     for (int c = 0; c < QT / 32; ++c) {
       f32x16_t st, dp;
@@ -556,8 +564,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
             boff = ((long long)hh * p.N + t * QT + 32 * c + 8 * g + 4 * hf + j) * p.N + k0 + r;
             sb = fmaf(p.bias[boff], LOG2E, sb);
           }
-          float pr = fast_exp2(fmaf(st[i], p.sl2, sb));
-          if (!BIAS && ragged && t == nt - 1 && t * QT + 32 * c + 8 * g + 4 * hf + j > last) pr = 0.f;   // padding query
+          const float pr = fast_exp2(fmaf(st[i], p.sl2, sb));                // (a padding query carries lse2 = +inf: pr = 0)
           const float dsu = pr * (dp[i] - dev[j]);                          // d(score): gradient of the bias entry too
           if constexpr (BIAS) {   // summed over the batch (skipped when the bias is a constant mask: dbias == NULL)
             typedef __attribute__((address_space(1))) float gfloat;

@@ -104,3 +104,29 @@ def test_headline_shape_training_step_bf16_vs_f32_gradients(setup):
         worst = min(worst, (cos, n))
         assert cos > 0.9, (n, cos)
     print("B=128 64x1024 bf16 vs f32 training-step gradients: worst cosine", worst)
+
+    # ---- and both against the ORACLE's backward at this shape: torch autograd over the CPU restatement on the full batch of
+    # 128 (float32, ~1-2 minutes of host time, ~40 GB of host memory).  Per tensor: relative L2 error and cosine; the
+    # float32 path must sit at rounding level (ReLU / arg-max flips of a few elements bound the L2 error, see smoke()).
+    import time
+    t0 = time.time()
+    loss_ref, _, gref, _ = O.loss_and_grads(s["sd"], s["cfg"], s["x"], s["targets"], s["lengths"], keep_mask=s["keep"], train=True)
+    print(f"oracle fwd+bwd on the full batch: {time.time() - t0:.0f} s, loss {loss_ref:.6f} (GPU float32 {l32:.6f})")
+    assert abs(l32 - loss_ref) < 1e-5 * abs(loss_ref)
+    worst32, worst16 = (0.0, None), (1.0, None)
+    for n, r in gref.items():
+        if n not in g32 or r.numel() < 64 or n.endswith("attn.qkv.bias"):
+            continue
+        r = r.flatten().double()
+        a32, a16 = g32[n].flatten().double(), g16[n].flatten().double()
+        e32 = float((a32 - r).norm() / (r.norm() + 1e-30))
+        c16 = float(a16 @ r / (a16.norm() * r.norm() + 1e-30))
+        worst32, worst16 = max(worst32, (e32, n)), min(worst16, (c16, n))
+        assert e32 < 2e-2, (n, e32)
+        assert c16 > 0.9, (n, c16)
+    for n in ("head.weight", "blocks.3.mlp.fc1.weight", "blocks.0.attn.qkv.weight", "patch_embed.layer3.1.conv2.weight",
+              "patch_embed.layer1.0.conv1.weight", "patch_embed.conv1.weight"):
+        r = gref[n].flatten().double()
+        print(f"   {n:40s} float32 rel-L2 {float((g32[n].flatten().double() - r).norm() / r.norm()):.3e}   "
+              f"bf16 cosine {float(g16[n].flatten().double() @ r / (g16[n].flatten().double().norm() * r.norm())):.5f}")
+    print("B=128 64x1024 gradients vs the oracle: float32 worst rel-L2", worst32, "| bf16 worst cosine", worst16)

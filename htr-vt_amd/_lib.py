@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("nB", i32), ("Hi", i32), ("Wi", i32), ("Ci", i32), ("Ho", i32), ("Wo", i32), ("Co", i32),
         ("kh", i32), ("kw", i32), ("sh", i32), ("sw", i32), ("ph", i32), ("pw", i32), ("Cpad", i32),
         ("cls_h", i32), ("cls_w", i32),
+        ("A2", vp),
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
         ("bias", vp), ("colscale", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
         ("relu_src", vp), ("bnb_x", vp * 2), ("bnb_mean", vp * 2), ("bnb_rstd", vp * 2), ("bnb_partial", vp * 2),
@@ -80,6 +81,7 @@ PROTOTYPES = {
     "htrvt_conv1_wgrad_blocks": (i32, [i32, i32]),
     "htrvt_conv1_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_pack_conv_weight": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "htrvt_pack_conv_weight_slots": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
     "htrvt_relpos_bias_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -685,7 +685,7 @@ constexpr int PK_CO = 16, PK_CI = 32, PK_MAXT = 9;
 template <typename T>
 __global__ __launch_bounds__(NT) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd,
                                                               T* __restrict__ dgr, int Co, int Ci, int taps, int cpi,
-                                                              int cpo) {
+                                                              int cpo, int row_taps, int tap0) {
   __shared__ float tile[PK_CO][PK_CI * PK_MAXT + 1];
   const int co0 = blockIdx.y * PK_CO, ci0 = blockIdx.x * PK_CI;
   const int run = PK_CI * taps;
@@ -699,13 +699,13 @@ __global__ __launch_bounds__(NT) void pack_conv_weight_kernel(const float* __res
   for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
     const int r = i / run, rem = i - r * run;
     const int t = rem / PK_CI, ci = rem - t * PK_CI;
-    if (co0 + r < Co && ci0 + ci < Ci) fwd[((long long)(co0 + r) * taps + t) * cpi + ci0 + ci] = from_f32<T>(tile[r][ci * taps + t]);
+    if (fwd != nullptr && co0 + r < Co && ci0 + ci < Ci) fwd[((long long)(co0 + r) * taps + t) * cpi + ci0 + ci] = from_f32<T>(tile[r][ci * taps + t]);
   }
   if (dgr != nullptr) {
     for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
       const int ci = i / (taps * PK_CO), rem = i - ci * taps * PK_CO;
       const int t = rem / PK_CO, r = rem - t * PK_CO;
-      if (co0 + r < Co && ci0 + ci < Ci) dgr[((long long)(ci0 + ci) * taps + t) * cpo + co0 + r] = from_f32<T>(tile[r][ci * taps + t]);
+      if (co0 + r < Co && ci0 + ci < Ci) dgr[((long long)(ci0 + ci) * row_taps + tap0 + t) * cpo + co0 + r] = from_f32<T>(tile[r][ci * taps + t]);
     }
   }
 }
@@ -973,8 +973,17 @@ extern "C" int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, in
   HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT, "pack_conv_weight: taps=%d unsupported (1..%d)", taps, PK_MAXT);
   dim3 grid((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO);
   DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
-                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out));
+                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out, taps, 0));
   return check_launch("pack_conv_weight");
+}
+
+extern "C" int htrvt_pack_conv_weight_slots(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
+                                            int cpad_out, int row_taps, int tap0, int dtype, void* stream) {
+  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT && tap0 >= 0 && tap0 + taps <= row_taps, "pack_conv_weight_slots: bad tap slots");
+  dim3 grid((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
+                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out, row_taps, tap0));
+  return check_launch("pack_conv_weight_slots");
 }
 
 extern "C" int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in,

@@ -481,6 +481,8 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.bnb_tile0 = d->bnb_tile0;
   const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   p.cls_h = p.cls_w = -1;
+  p.extra_off = 0;
+  HTRVT_REQUIRE(d->A2 == nullptr || cls, "htrvt_gemm: A2 needs a parity-class dgrad launch");
   p.Hq = d->Hi; p.Wq = d->Wi;
   p.ntapsel = d->kh * d->kw;
   for (int t = 0; t < 12; ++t) p.tapsel[t] = (unsigned char)t;
@@ -493,6 +495,14 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
       for (int dx = 0; dx < d->kw; ++dx)
         if ((d->cls_h + d->ph - dy) % d->sh == 0 && (d->cls_w + d->pw - dx) % d->sw == 0)
           p.tapsel[p.ntapsel++] = (unsigned char)(dy * d->kw + dx);
+    if (d->A2 != nullptr) {
+      HTRVT_REQUIRE(d->cls_h == 0 && d->cls_w == 0, "htrvt_gemm: A2 (1x1 downsample gradient) goes with the class (0, 0) launch only");
+      const long long diff = (const char*)d->A2 - (const char*)d->A;
+      HTRVT_REQUIRE(diff > 0 && diff + (long long)d->nB * d->Ho * d->Wo * d->Co * 2 < (1ll << 31) - 64,
+                    "htrvt_gemm: A2 must lie behind A, both inside 2 GiB");
+      p.tapsel[p.ntapsel++] = (unsigned char)(d->kh * d->kw);       // one more tap: rows kh*kw of the packed weight
+      p.extra_off = (unsigned)diff;
+    }
     HTRVT_REQUIRE(d->M == d->nB * p.Hq * p.Wq && d->K == p.ntapsel * d->Cpad && d->N == d->Ci,
                   "htrvt_gemm: parity-class dgrad extents inconsistent (expected M=%d K=%d)", d->nB * p.Hq * p.Wq,
                   p.ntapsel * d->Cpad);

@@ -61,7 +61,7 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   if (d->dtype != HTRVT_BF16 || d->M <= 128) return false;
   if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
   if (d->gather != HTRVT_GATHER_NONE && d->gather != HTRVT_GATHER_CONV_FWD && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;
-  if (d->split_k > 1 || d->accumulate || d->c_f32) return false;
+  if (d->split_k > 1 || d->accumulate || d->c_f32 || d->A2 != nullptr) return false;
   if (!extents_ok(d)) return false;
   const int bn = gemm8p_pick_bn(d);
   const int cw = bn == 256 ? 8 : 12;     // consecutive columns a lane stores

@@ -50,6 +50,9 @@ struct KParams {
   // the same list, 4 bits per entry, as ONE 64-bit scalar: indexing the kernarg array with the k-tile's tap position
   // compiled to a global byte load + s_waitcnt vmcnt(0) inside the loader waves' issue path, twice per k-tile
   unsigned long long tappack;
+  // HtrvtGemmDesc.A2: byte distance from A to the second gathered tensor, read through tap code kh*kw (the 1x1
+  // downsample gradient as one more tap of the class-(0,0) launch); 0 without one
+  unsigned extra_off;
   // fused backward-of-ReLU and BatchNorm-backward column sums in the bf16 staged epilogue (conv dgrad outputs)
   const char* relu_src;
   const char* bnb_x[2];

@@ -190,6 +190,12 @@ struct DmaLoader {
       cbase = k0 - ti * p.Cpad;
       tap_dy = tap / p.kw;
       tap_dx = tap - tap_dy * p.kw;
+      unsigned xoff = 0;
+      if (ROLE == 2 && tap >= p.kh * p.kw) {   // the extra tap: the 1x1 downsample gradient (A2), at the centre tap's pixel
+        tap_dy = p.ph;
+        tap_dx = p.pw;
+        xoff = p.extra_off;
+      }
       if constexpr (KMAP) cbase += tap * p.Cpad;  // column of the packed weight matrix
       if constexpr (ROLE == 1 || ROLE == 2) {
         if (ti != cur_ti) {  // wave-uniform: entering a new tap
@@ -209,7 +215,7 @@ struct DmaLoader {
                   (wo < p.Wo);
               off += (unsigned)((ho * p.Wo + wo) * p.Co + c2[i]) * 2;
             }
-            tapoff[i] = v ? off : OOB;
+            tapoff[i] = v ? off + xoff : OOB;
           }
         }
       }

@@ -89,6 +89,10 @@ class Engine:
         # under the (HBM-bound) image statistics, conv1 and max-pool kernels, instead of ~30 latency-bound launches in
         # front of their first use
         self.prefetch_packs = True
+        # first block of a stage, bf16: the input gradient of the 1x1 downsample conv is formed INSIDE the class-(0,0) launch
+        # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
+        # plus a residual round trip of the whole input gradient
+        self.fuse_downsample_dgrad = True
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
@@ -185,6 +189,25 @@ class Engine:
                   "pack_conv_weight")
             self._packs[name] = (key, (fwd, dgr))
             return fwd, dgr
+        return ent[1]
+
+    def _conv_w_joint_dgrad(self, name, w3, namd, wd):
+        """[Ci][taps + 1][Cpad_o] dgrad pack shared by a block's strided 3x3 conv (tap slots 0 .. taps-1) and its 1x1 downsample
+        conv (slot `taps`): the B operand of the parity-class dgrad launches when the downsample gradient rides along as one
+        more tap (HtrvtGemmDesc.A2, conv_dgrad(extra=...))."""
+        key = (self._wkey(w3), self._wkey(wd))
+        ent = self._packs.get(name + "+ds")
+        Co, Ci, kh, kw = w3.shape
+        taps = kh * kw
+        cpi, cpo = cpad(Ci, self.dtype), cpad(Co, self.dtype)
+        if ent is None or ent[0] != key:
+            buf = ent[1] if ent is not None else torch.zeros(Ci, taps + 1, cpo, dtype=self.dtype, device=self.dev)
+            check(lib.htrvt_pack_conv_weight_slots(ptr(w3), None, ptr(buf), Co, Ci, taps, cpi, cpo, taps + 1, 0, self.dti, stream()),
+                  "pack_conv_weight_slots")
+            check(lib.htrvt_pack_conv_weight_slots(ptr(wd), None, ptr(buf), Co, Ci, 1, cpi, cpo, taps + 1, taps, self.dti, stream()),
+                  "pack_conv_weight_slots")
+            self._packs[name + "+ds"] = (key, buf)
+            return buf
         return ent[1]
 
     # ------------------------------------------------------------------ GEMM-shaped pieces
@@ -300,10 +323,14 @@ class Engine:
     def _dgrad_by_class(self, g):
         return self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
 
-    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None):
-        """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only)"""
+    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None):
+        """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only).
+        extra = dy2 (parity-class path only): the gradient of the block's 1x1 downsample conv output, allocated right
+        behind dy; wd is then the joint pack of _conv_w_joint_dgrad and dx also receives the 1x1 conv's input gradient."""
         cpo = cpad(g.Co, self.dtype)
         dx = self._empty(g.B, g.Hi, g.Wi, g.Ci)
+        assert extra is None or self._dgrad_by_class(g)
+        wtaps = g.taps + (1 if extra is not None else 0)       # taps per row of the packed weight
         if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
             tile0 = 0
@@ -322,10 +349,11 @@ class Engine:
                     if st_ is not main:
                         st_.wait_stream(main)
                         used.append(st_)
+                    a2 = extra if (extra is not None and (a, b) == (0, 0)) else None    # the pixels a 1x1 stride-s conv reads
                     with torch.cuda.stream(st_):
-                        gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=nt * cpo, lda=g.Co, ldb=g.taps * cpo,
-                             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(a, b),
-                             relu_src=relu_src, bnb=bnb, bnb_tile0=tile0)
+                        gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=(nt + (1 if a2 is not None else 0)) * cpo,
+                             lda=g.Co, ldb=wtaps * cpo, ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual,
+                             cls=(a, b), relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, a2=a2)
                     tile0 += ops.gemm_num_mtiles(g.B * Hq * Wq, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
             for st_ in used:       # every class has written its pixels before anything downstream reads dx
                 main.wait_stream(st_)
@@ -370,7 +398,7 @@ class Engine:
                                  x.numel() // C, C, 1 if relu else 0, self.dti, stream()), "bn_apply")
         return y
 
-    def bn_backward(self, dy, yact, x, prefix, P, G, mean, rstd, want_g=False):
+    def bn_backward(self, dy, yact, x, prefix, P, G, mean, rstd, want_g=False, out=None):
         """dx of train-mode BN (+ReLU mask from yact); accumulates dgamma/dbeta into G.  Unfused form: one
         reduction pass over (dy, yact, x), then bn_backward_finish."""
         C = x.shape[-1]
@@ -379,9 +407,9 @@ class Engine:
         partial = self._empty(nblk, 2, C, dtype=torch.float32)
         check(lib.htrvt_bn_bwd_reduce(ptr(dy), ptr(yact), ptr(x), ptr(mean), ptr(rstd), ptr(partial), npix, C, self.dti,
                                       stream()), "bn_bwd_reduce")
-        return self.bn_backward_finish(partial, nblk, dy, yact, x, prefix, P, G, mean, rstd, want_g)
+        return self.bn_backward_finish(partial, nblk, dy, yact, x, prefix, P, G, mean, rstd, want_g, out=out)
 
-    def bn_backward_finish(self, partial, rows, g, yact, x, prefix, P, G, mean, rstd, want_g=False):
+    def bn_backward_finish(self, partial, rows, g, yact, x, prefix, P, G, mean, rstd, want_g=False, out=None):
         """finalize (dgamma, dbeta, coefficients) from per-tile partial sums, then dx = cA*g + cB*x + cC.
         With yact=None, g is the already ReLU-masked gradient (fused dgrad epilogue)."""
         C = x.shape[-1]
@@ -396,7 +424,7 @@ class Engine:
         check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, count, ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
                                         ptr(G[prefix + ".weight"]), ptr(G[prefix + ".bias"]), ptr(coef), stream()),
               "bn_bwd_finalize")
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if out is None else out
         gout = torch.empty_like(x) if want_g else None
         check(lib.htrvt_bn_bwd_apply(ptr(g), ptr(yact), ptr(x), ptr(coef), ptr(dx), ptr(gout), npix, C, self.dti, stream()),
               "bn_bwd_apply")
@@ -464,6 +492,10 @@ class Engine:
             with torch.cuda.stream(self._side):
                 for name, _ci, _co, _k, _st, _pd in s.stem_convs():
                     self._conv_w(name, P[name + ".weight"])
+                if save and self.fuse_downsample_dgrad:
+                    for li in (1, 2, 3):
+                        pb = f"patch_embed.layer{li}.0"
+                        self._conv_w_joint_dgrad(pb + ".conv1", P[pb + ".conv1.weight"], pb + ".downsample.0", P[pb + ".downsample.0.weight"])
                 for name in s.linears():
                     if name == "head":
                         self._head_w(P["head.weight"])
@@ -758,17 +790,22 @@ class Engine:
                 parts_d = parts[1] if len(parts) > 1 else None
             _, wd2 = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
             self.conv_wgrad(dcb, blk["a1"], blk["g2"], G[p + ".conv2.weight"])
+            # downsample gradient as one more tap of the strided conv's class-(0,0) dgrad: d(conv1 out) and d(downsample
+            # out) then live back to back in one allocation (the second gather source sits at a fixed offset from the first)
+            fuse_ds = self.fuse_downsample_dgrad and blk["gd"] is not None and self._dgrad_by_class(blk["g1"])
+            pair = self._empty(2, *blk["ca"].shape) if fuse_ds else None
+            dca_out = pair[0] if fuse_ds else None
             if can_fuse(blk["g2"]):
                 rows1 = self.dgrad_tiles(blk["g2"])
                 part1 = self._empty(rows1, 2, C, dtype=torch.float32)
                 g1 = self.conv_dgrad(dcb, wd2, blk["g2"], relu_src=blk["a1"],
                                      bnb=[(blk["ca"], blk["bn_a"][2], blk["bn_a"][3], part1)])
                 dca, _ = self.bn_backward_finish(part1, rows1, g1, None, blk["ca"], p + ".bn1", P, G, blk["bn_a"][2],
-                                                 blk["bn_a"][3])
+                                                 blk["bn_a"][3], out=dca_out)
                 del g1
             else:
                 da1 = self.conv_dgrad(dcb, wd2, blk["g2"])
-                dca, _ = self.bn_backward(da1, blk["a1"], blk["ca"], p + ".bn1", P, G, blk["bn_a"][2], blk["bn_a"][3])
+                dca, _ = self.bn_backward(da1, blk["a1"], blk["ca"], p + ".bn1", P, G, blk["bn_a"][2], blk["bn_a"][3], out=dca_out)
                 del da1
             del dcb
             _, wd1 = self._conv_w(p + ".conv1", P[p + ".conv1.weight"])
@@ -784,15 +821,22 @@ class Engine:
                 kw = dict(relu_src=prev["out"], bnb=[(x_, m_, r_, b_) for (x_, m_, r_), b_ in zip(req, bufs)])
                 parts = [(b_, rows) for b_ in bufs]
             if blk["gd"] is not None:
+                dcd_out = pair[1] if fuse_ds else None
                 if parts_d is not None:
                     dcd, _ = self.bn_backward_finish(parts_d[0], parts_d[1], gm, None, blk["cd"], p + ".downsample.1", P, G,
-                                                     blk["bn_d"][2], blk["bn_d"][3])
+                                                     blk["bn_d"][2], blk["bn_d"][3], out=dcd_out)
                 else:
-                    dcd, _ = self.bn_backward(gm, None, blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3])
+                    dcd, _ = self.bn_backward(gm, None, blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3],
+                                              out=dcd_out)
                 _, wdd = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
                 self.conv_wgrad(dcd, blk["x"], blk["gd"], G[p + ".downsample.0.weight"])
-                dres = self.conv_dgrad(dcd, wdd, blk["gd"])
-                dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=dres, **kw)
+                if fuse_ds:
+                    wdj = self._conv_w_joint_dgrad(p + ".conv1", P[p + ".conv1.weight"], p + ".downsample.0",
+                                                   P[p + ".downsample.0.weight"])
+                    dout = self.conv_dgrad(dca, wdj, blk["g1"], extra=dcd, **kw)
+                else:
+                    dres = self.conv_dgrad(dcd, wdd, blk["gd"])
+                    dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=dres, **kw)
             else:
                 dout = self.conv_dgrad(dca, wd1, blk["g1"], residual=gm, **kw)
 

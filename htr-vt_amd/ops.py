@@ -67,7 +67,7 @@ class ConvGeom:
 def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
          Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
          accumulate=False, bias=None, colscale=None, preact=None, residual=None, colstats=None, tile=0,
-         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0, splitk_ws=None):
+         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0, splitk_ws=None, a2=None):
     """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
     is used); *_off are element offsets into them."""
     d = GemmDesc()
@@ -82,6 +82,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.split_k = split_k
     d.splitk_ws = ptr(splitk_ws)    # float32 [split_k][M][N]: reproducible split-K (ordered slab sum, no atomics)
     d.cls_h, d.cls_w = (-1, -1) if cls is None else cls
+    d.A2 = ptr(a2)          # class-(0,0) dgrad: the block's 1x1 downsample gradient as one more tap (include/htrvt.h)
     if geom is not None:
         geom.fill(d)
         d.Cpad = Cpad

@@ -67,6 +67,13 @@ typedef struct HtrvtGemmDesc {
    * cls_h/cls_w in [0,sh)/[0,sw) select the pixels hi%sh==cls_h, wi%sw==cls_w (M = their count, row-major over
    * (b, hi/sh, wi/sw)); K = (#taps that can reach this class) * Cpad (may be 0).  cls_h = -1: all pixels/taps. */
   int32_t cls_h, cls_w;
+  /* Parity-class dgrad of class (0, 0) only, or NULL: A2 = the gradient of the block's 1x1 downsample convolution output
+   * (resnet18.py:59-63: same stride, padding 0, same [B,Ho,Wo,Co] shape as A, allocated BEHIND A within 2 GiB).  Its
+   * input gradient lands on exactly the class-(0,0) pixels, through the pixel the centre tap of the 3x3 reaches, so it is
+   * contracted as ONE MORE TAP: K = (#taps of the class + 1) * Cpad, and B holds kh*kw + 1 taps per row (ldb =
+   * (kh*kw + 1) * Cpad), the last one the packed 1x1 weight.  Replaces a separate 1x1 dgrad (one launch per class, three
+   * of them without a single tap) plus a residual round trip of the whole input gradient. */
+  const void* A2;
   /* epilogue */
   float alpha;
   int32_t act;              /* 0 none, 1 exact-erf GELU, 2 multiply by GELU'(preact), 3 ReLU applied last (after residual) */
@@ -247,6 +254,10 @@ int htrvt_relpos_bias_bwd(const float* dbias, float* dtable, int N, int num_patc
 /* w [Co][Ci][taps] float32 -> fwd [Co][taps][cpad_in], dgrad [Ci][taps][cpad_out] (may be NULL); pads untouched */
 int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
                            int cpad_out, int dtype, void* stream);
+/* the same with the dgrad pack written into tap slots tap0 .. tap0+taps-1 of rows that hold row_taps taps:
+ * dgrad [Ci][row_taps][cpad_out] (a 3x3 weight and its block's 1x1 downsample weight share one buffer, see A2 above) */
+int htrvt_pack_conv_weight_slots(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in, int cpad_out,
+                                 int row_taps, int tap0, int dtype, void* stream);
 /* grad [Co][Ci][taps] += packed [taps][cpad_in][Co]  (the conv-wgrad GEMM output) */
 int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in, void* stream);
 int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);

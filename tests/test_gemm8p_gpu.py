@@ -199,3 +199,51 @@ def test_halo_conv_forward_dgrad_exact(cfg):
         assert torch.equal(dxd.double().cpu(), x.grad.permute(0, 2, 3, 1).to(BF).double()), (tile, _last_kernel())
     if Ci >= 96:       # the dgrad's N = Ci: 192- or 128-column tiles -> the halo kernel must have run under tile 12
         assert "gemm_halo_kernel" in outs[12] or "gemm_halo_kernel" in _last_kernel(), (outs, _last_kernel())
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# first block of a stage (resnet18.py:33-37,59-63): the input gradient of the 1x1 stride-s downsample conv formed inside
+# the class-(0,0) launch of the strided 3x3 conv's parity-class dgrad (HtrvtGemmDesc.A2: one more tap)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(2, 8, 128, 192, 384, (2, 2)), (2, 16, 128, 192, 192, (2, 1)), (3, 4, 192, 384, 768, (2, 2)),
+                                 (2, 8, 144, 192, 384, (2, 2))])
+@pytest.mark.parametrize("fused_epilogue", [False, True])
+def test_strided_dgrad_with_downsample_gradient_as_extra_tap(cfg, fused_epilogue):
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd.engine import Engine, ModelShape
+    ops = T._ops()
+    Bn, Hi, Wi, Ci, Co, stride = cfg
+    eng = Engine(ModelShape(80, (64, 512), 64, 2, 2), BF, "cuda")
+    g3 = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, 3, stride, 1)
+    gd = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, 1, stride, 0)
+    assert (g3.Ho, g3.Wo) == (gd.Ho, gd.Wo)
+    w3 = T._sparse_ints((Co, Ci, 3, 3), 60)
+    wd = T._sparse_ints((Co, Ci, 1, 1), 61)
+    dy3 = T._sparse_ints((Bn, Co, g3.Ho, g3.Wo), 62)
+    dyd = T._sparse_ints((Bn, Co, g3.Ho, g3.Wo), 63)
+    dx = (torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), w3, dy3, stride=stride, padding=1)
+          + torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), wd, dyd, stride=stride, padding=0)).permute(0, 2, 3, 1)
+    pair = torch.empty(2, Bn, g3.Ho, g3.Wo, Co, dtype=BF, device="cuda")
+    pair[0].copy_(dy3.permute(0, 2, 3, 1).to(BF))
+    pair[1].copy_(dyd.permute(0, 2, 3, 1).to(BF))
+    wj = eng._conv_w_joint_dgrad("t3", w3.float().cuda(), "td", wd.float().cuda())
+    assert wj.shape == (Ci, 10, ops.cpad(Co, BF))
+    kw, want = {}, dx
+    if fused_epilogue:
+        relu_src = T._ints((Bn, Hi, Wi, Ci), -1, 2, seed=64)
+        bnx = T._ints((Bn, Hi, Wi, Ci), -4, 5, seed=65)
+        gen = torch.Generator().manual_seed(66)
+        mean = torch.randint(-2, 3, (Ci,), generator=gen).double()
+        rstd = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (Ci,), generator=gen)].double()
+        rows = eng.dgrad_tiles(g3)
+        part = torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda")
+        kw = dict(relu_src=relu_src.to(BF).cuda(), bnb=[(bnx.to(BF).cuda(), mean.float().cuda(), rstd.float().cuda(), part)])
+        want = dx * (relu_src > 0)
+    assert want.abs().max() < 256
+    out = eng.conv_dgrad(pair[0], wj, g3, extra=pair[1], **kw)
+    assert torch.equal(out.double().cpu(), want), float((out.double().cpu() - want).abs().max())
+    if fused_epilogue:      # the partial sums of all class launches together = the sums over the whole gradient
+        got = part.double().cpu().sum(0)
+        xhat = (bnx - mean) * rstd
+        assert torch.equal(got[0], want.reshape(-1, Ci).sum(0))
+        assert torch.equal(got[1], (want * xhat).reshape(-1, Ci).sum(0))

@@ -432,14 +432,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p,
             st[4 * g + j] = pr * (dp[4 * g + j] - dl) * p.scale;
           }
         }
-      } else if (ragged && t == nt - 1) {               // workgroup-uniform: the tile with the padding keys
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));
-          if (t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) pr = 0.f;
-          st[i] = pr * (dp[i] - dl) * p.scale;
-        }
       } else {
+        if (ragged && t == nt - 1) {       // workgroup-uniform: scores of the padding keys -> -inf, their probability is 0
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (t * KT + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf > last) st[i] = -INFINITY;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float pr = fast_exp2(fmaf(st[i], p.sl2, -lse));

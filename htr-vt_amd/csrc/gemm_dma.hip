@@ -11,6 +11,7 @@ int gemm_dma_dispatch_bn128_s3(const HtrvtGemmDesc*, const KParams&, int, hipStr
 int gemm_dma_dispatch_bn192(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_dma_dispatch_bn256(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_halo_try_launch(const HtrvtGemmDesc*, const KParams&, int bn, hipStream_t);
+int gemm_hwgrad_try_launch(const HtrvtGemmDesc*, KParams&, int zdim, hipStream_t);
 }  // namespace htrvt
 
 namespace {
@@ -82,6 +83,10 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
     // per-column scale / trailing ReLU exist in the staged bf16 epilogue of the conv-forward kernels only
     if (d->gather != HTRVT_GATHER_CONV_FWD || d->c_f32 || (d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;
     if (d->batch > 1 && ((d->sC_o | d->sC_i) & 7)) return 0;
+  }
+  if (d->gather == HTRVT_GATHER_CONV_WGRAD) {   // 3x3 stride-1 convolutions: halo-staged x operand (gemm_hwgrad_impl.h)
+    const int r = gemm_hwgrad_try_launch(d, p, zdim, st);
+    if (r != 0) return r;
   }
   const int bn = pick_bn(d);
   p.tiles_m = (d->M + BM_ - 1) / BM_;

@@ -1,0 +1,42 @@
+// gemm_hwgrad.hip -- instantiations + host-side eligibility of the halo-staged 3x3 stride-1 conv weight-gradient kernels
+// (gemm_hwgrad_impl.h); called from gemm_dma_try_launch before the generic MN-major gather kernel.
+#include "gemm_hwgrad_impl.h"
+
+namespace htrvt {
+
+// channel chunk of the tile: 128 where it divides the padded channel count, else 64
+int gemm_hwgrad_cc(const HtrvtGemmDesc* d) { return d->Cpad % 128 == 0 ? 128 : 64; }
+int gemm_hwgrad_bn(const HtrvtGemmDesc* d) {
+  const int p192 = (d->N + 191) / 192 * 192, p128 = (d->N + 127) / 128 * 128;
+  return p192 <= p128 ? 192 : 128;
+}
+
+bool gemm_hwgrad_serves(const HtrvtGemmDesc* d) {
+  if (d->gather != HTRVT_GATHER_CONV_WGRAD || d->dtype != HTRVT_BF16) return false;
+  if (d->tile != 0 && d->tile != 13) return false;      // 13: this kernel where eligible; 3 / 4 / 6: the generic kernels (A/B)
+  if (d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
+  if (d->Ho != d->Hi || d->Wo != d->Wi || (d->Wi % 64) != 0) return false;     // a k-tile = 64 pixels of one image row
+  if (!d->c_f32 || d->batch > 1 || d->Cpad % 64 != 0 || d->M != 9 * d->Cpad || d->N != d->Co) return false;
+  if (d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr) return false;
+  const long long lim = (1ll << 31) - 64;
+  if ((long long)d->nB * d->Hi * d->Wi * d->Ci * 2 >= lim || (long long)d->K * d->ldb * 2 >= lim) return false;
+  return true;
+}
+
+// work groups per pixel range (for the split-K heuristic of the caller)
+int gemm_hwgrad_tiles(const HtrvtGemmDesc* d) {
+  return 3 * (d->Cpad / gemm_hwgrad_cc(d)) * ((d->N + gemm_hwgrad_bn(d) - 1) / gemm_hwgrad_bn(d));
+}
+
+int gemm_hwgrad_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
+  if (!gemm_hwgrad_serves(d)) return 0;
+  const int cc = gemm_hwgrad_cc(d), bn = gemm_hwgrad_bn(d);
+  p.tiles_n = (d->N + bn - 1) / bn;
+  p.tiles_m = 3 * (d->Cpad / cc);
+  if (cc == 128 && bn == 192) return launch_hwgrad<128, 192>(p, zdim, st);
+  if (cc == 128 && bn == 128) return launch_hwgrad<128, 128>(p, zdim, st);
+  if (cc == 64 && bn == 192) return launch_hwgrad<64, 192>(p, zdim, st);
+  return launch_hwgrad<64, 128>(p, zdim, st);
+}
+
+}  // namespace htrvt

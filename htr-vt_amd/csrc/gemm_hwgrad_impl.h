@@ -1,0 +1,226 @@
+// gemm_hwgrad_impl.h -- weight gradient of the 3x3, stride-1, pad-1 convolutions (resnet18.py:26-31 backward, nine of the
+// twelve 3x3 convolutions of the stem) with a HALO-STAGED x operand.
+//
+//   dW[dy][dx][ci][co] = sum over pixels (b, h, w) of  x[b, h + dy - 1, w + dx - 1, ci] * dY[b, h, w, co]
+//
+// As a GEMM (gemm_dma_impl.h, GATHER 3) this is M = taps * Cpad rows (tap, ci), N = Co, K = pixels with both operands
+// MN-major, and every k-tile of 64 pixels stages a 64 x 256 x-tile in which neighbouring taps hold the SAME pixels shifted
+// by one: 56 KB of LDS-DMA per 256 x 192 x 64 MACs, on a path whose per-CU rate (~45 GB/s with everything else going on)
+// bounds the loop -- ablation in DESIGN.md 5: MFMA side alone 0.52 ms, DMA alone 0.57 ms, together 0.80 ms.
+// Here a workgroup owns ONE kernel row dy, CC input channels, BN output channels and computes all three taps dx of that
+// row: per k-tile (64 consecutive pixels of one image row; host check W % 64 == 0) it stages
+//   X : the 66 pixels w0-1 .. w0+64 of image row h + dy - 1, CC channels   ([pixel][channel], 8.4 / 16.9 KB)
+//   DY: the 64 pixels x BN channels of the output gradient                 ([pixel][channel], 24.6 KB at BN = 192)
+// and the MFMA waves of tap dx read their A fragments dx pixel-rows further down the X tile.  Output tile (3 * CC) x BN:
+// 41 KB per 384 x 192 x 64 MACs at CC = 128 (-52 % operand bytes per FLOP), 33 KB per 192 x 192 x 64 at CC = 64 (-22 %).
+// The smaller stages leave room for THREE of them: the DMA of k-tile t+2 is issued while t is multiplied and the wait before
+// the barrier is a counted vmcnt that leaves it in flight.
+// 12 waves (6 along M x 2 along N, 64 x 96 or 32 x 96 outputs each, v_mfma_f32_32x32x16_bf16, operands by transposed LDS
+// reads), every wave issues its share of the DMA; split-K over pixel ranges with the float32 epilogue (atomics or
+// per-range slabs) of the generic kernel, XCD-grouped like there.
+#pragma once
+#include "gemm_dma_impl.h"
+
+namespace {
+
+template <int CC, int BN>
+struct HwGeo {
+  static constexpr int NW = 12, NTH = NW * 64;
+  static constexpr int BM = 3 * CC;                       // output rows of a tile: (dx, channel)
+  static constexpr int XROWB = CC * 2, XCPR = CC / 8;     // X tile row: bytes, 16-byte chunks
+  static constexpr int XRPP = 1024 / XROWB;               // pixel rows per DMA piece (4 at CC = 128, 8 at CC = 64)
+  static constexpr int XPIECES = (66 + XRPP - 1) / XRPP;  // 17 / 9
+  static constexpr int XBYTES = XPIECES * 1024;
+  static constexpr int YBYTES = Geo<BN, NW>::BYTES, YPIECES = YBYTES / 1024;
+  static constexpr int STAGE = XBYTES + YBYTES;
+  static constexpr int NSTAGE = 3;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE;
+  static constexpr int TM = CC / 64, TN = BN / 64;        // 32x32 tiles per wave: rows (CC / 2 per wave -> 64 or 32), columns BN / 2
+  static constexpr int WROWS = CC / 2;                    // rows per wave
+  static_assert(CC == 64 || CC == 128, "channel chunk");
+  static constexpr int NWY = YPIECES % NW == 0 ? NW : 8;   // waves that issue dY pieces (24 pieces: all 12; 16 pieces: 8)
+  static_assert(YPIECES % NWY == 0, "dY pieces divide over the issuing waves");
+  static constexpr int NPY = YPIECES / NWY;
+  static constexpr int NPX_MAX = (XPIECES + NW - 1) / NW; // waves 0 .. XPIECES - NW*(NPX_MAX-1) - 1 issue NPX_MAX pieces, the rest one fewer
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  // rotation (16-byte chunks) of X pixel row r: the four rows a transposed read of a half-wave touches must land on four
+  // different 64-byte bank groups: 256-byte rows -> 4 * (r & 3); 128-byte rows (two per bank line) -> 4 * ((r >> 1) & 1)
+  static __device__ __forceinline__ int xrot(int r) { return CC == 128 ? 4 * (r & 3) : 4 * ((r >> 1) & 1); }
+};
+
+template <int CC, int BN, class P>
+__device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) {
+  using H = HwGeo<CC, BN>;
+  using T = bf16_t;
+  constexpr int TM = H::TM, TN = H::TN, NW = H::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int NCC = p.Cpad / CC;
+  const int tiles_m = 3 * NCC;                       // (kernel row, channel chunk)
+  const int ntiles = tiles_m * p.tiles_n;
+  int id = block_x, z = blockIdx.z;
+  if (p.split_k > 1 && (p.split_k & 7) == 0) {       // all tiles of one pixel range on one XCD (they read the same x / dY rows)
+    const int chunk = block_x / (8 * ntiles), r = block_x - chunk * 8 * ntiles;
+    z = chunk * 8 + (r & 7);
+    id = r >> 3;
+  }
+  const int tm = id / p.tiles_n, tile_n = id - tm * p.tiles_n;
+  const int dyi = tm / NCC, ci0 = (tm - dyi * NCC) * CC;
+  const int n0 = tile_n * BN;
+  int kbeg = 0, kend = p.K;
+  long long coff = 0;
+  if (p.split_k > 1) {
+    kbeg = z * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+    coff = (long long)z * p.slab_stride;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;           // 6 x 2
+  const int dx = wm / (CC / 64 * 1 + (CC == 64 ? 1 : 0));   // CC = 128: two waves per tap; CC = 64: two waves per tap as well (32 rows each)
+  const int crow = (wm & 1) * H::WROWS;              // first channel of this wave inside the chunk
+
+  // ---- DMA bookkeeping ----
+  DmaLoader<BN, HTRVT_MNMAJOR, 0, H::NWY> ly;        // dY: plain MN-major rows (k = pixel)
+  const bool yload = wave < H::NWY;                  // wave-uniform
+  ly.init(p, p.B, p.ldb, n0, p.N, yload ? wave : 0, lane);
+  const unsigned long long xa = (unsigned long long)p.A;
+  const i32x4_t rsrcX = i32x4_t{(int)(unsigned)(xa & 0xffffffffull), (int)(unsigned)((xa >> 32) & 0xffffull), (int)OOB, 0x00020000};
+  const int npx = (wave < H::XPIECES - NW * (H::NPX_MAX - 1)) ? H::NPX_MAX : H::NPX_MAX - 1;   // wave-uniform
+  const int per_tile = npx + (wave < H::NWY ? H::NPY : 0);      // DMA pieces this wave issues per k-tile
+  auto wait_one_tile_in_flight = [&]() {   // everything but this wave's newest k-tile has landed (the count is an immediate)
+    switch (per_tile) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    }
+  };
+  static_assert(H::NPX_MAX + H::NPY <= 5, "vmcnt switch");
+  const unsigned lds0 = lds_addr_of(smem);
+  const int Hh = p.Hi, Ww = p.Wi;
+  // k-tile position of the NEXT tile to issue: flattened pixel kq = (b * H + h) * W + w0, kept as (row = b*H + h, w0)
+  int iq_row = kbeg / Ww, iq_w0 = kbeg - iq_row * Ww, iq_k = kbeg;
+  auto issue = [&](int stage) {
+    const unsigned sbase = lds0 + stage * H::STAGE;
+    const int hrow = iq_row % Hh;
+    const int hh = hrow + dyi - 1;
+    const bool rowok = iq_k < kend && (unsigned)hh < (unsigned)Hh;
+    const unsigned gbase = (unsigned)(((iq_row - hrow + hh) * Ww + iq_w0 - 1) * p.Ci + ci0) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+#pragma unroll
+    for (int i = 0; i < H::NPX_MAX; ++i) {
+      if (i < npx) {      // wave-uniform
+        const int pi = wave + NW * i;
+        const int r = pi * H::XRPP + lane / H::XCPR;           // pixel row of the halo tile
+        const int cd = lane % H::XCPR;
+        int cs = cd - H::xrot(r);
+        cs += cs < 0 ? H::XCPR : 0;
+        const int w = iq_w0 - 1 + r;
+        const bool v = rowok && r < 66 && (unsigned)w < (unsigned)Ww && ci0 + cs * 8 < p.Ci;
+        const unsigned voff = v ? gbase + (unsigned)(r * p.Ci + cs * 8) * 2u : OOB;
+        dma16(rsrcX, __builtin_amdgcn_readfirstlane(sbase + pi * 1024), voff);
+      }
+    }
+    if (yload) ly.template issue<false>(p, sbase + H::XBYTES, iq_k, kend, wave);
+    iq_k += BK;
+    iq_w0 += BK;
+    if (iq_w0 >= Ww) {
+      iq_w0 = 0;
+      ++iq_row;
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  issue(0);
+  issue(1);
+  wait_one_tile_in_flight();      // tile 0 landed, tile 1 may fly
+  __builtin_amdgcn_s_barrier();
+
+  // transposed A fragment: rows = channels crow + 32 i + (lane & 31) of tap dx, k = pixels 16 s + ... of the k-tile ->
+  // X tile pixel row (k + dx), read by two ds_read_b64_tr_b16 (4 pixel rows each)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hq = g >> 1;
+  auto xfrag = [&](const char* xs, int i, int s) {
+    const int r0 = 16 * s + 8 * hq + q + dx;                 // pixel row of the first read; the second is 4 further
+    const int cb = (crow + 32 * i) / 8 + 2 * (g & 1) + (pp >> 1);
+    int c0 = cb + H::xrot(r0), c1 = cb + H::xrot(r0 + 4);
+    c0 -= c0 >= H::XCPR ? H::XCPR : 0;
+    c1 -= c1 >= H::XCPR ? H::XCPR : 0;
+    typedef __attribute__((address_space(3))) s16x4_t* lptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + r0 * H::XROWB + c0 * 16 + (pp & 1) * 8));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + (r0 + 4) * H::XROWB + c1 * 16 + (pp & 1) * 8));
+    const s16x8_t r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+
+  int cur = 0, nxt = 2;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* xs = smem + cur * H::STAGE;
+    const char* ys = xs + H::XBYTES;
+    issue(nxt);            // k-tile kt + 2 (zero fill past the range): its stage was read in k-tile kt - 1
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = xfrag(xs, i, s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, HTRVT_MNMAJOR>(ys, wn * TN + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    wait_one_tile_in_flight();
+    __builtin_amdgcn_s_barrier();
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // rows of the packed weight gradient [tap][Cpad][Co]: m = (dy * 3 + dx) * Cpad + ci0 + channel
+  const int mrow0 = (dyi * 3 + dx) * p.Cpad + ci0 + crow;
+  gemm_epilogue<T, TM, TN, 1, BN, H::NTH, false>(acc, p, p.C, coff, mrow0, n0 + wn * TN * 32, 0, n0, 0, lane, smem, true);
+}
+
+template <int CC, int BN>
+__global__ __launch_bounds__(768) void gemm_hwgrad_kernel(const KParams p) {
+  typedef const __attribute__((address_space(4))) KParams KP;
+  (void)p;
+  KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+  gemm_hwgrad_body<CC, BN>(*kp, (int)blockIdx.x);
+}
+
+template <int CC, int BN>
+int launch_hwgrad(const KParams& p, int zdim, hipStream_t st) {
+  using H = HwGeo<CC, BN>;
+  static bool attr_done = false;
+  auto kern = gemm_hwgrad_kernel<CC, BN>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(%d B LDS): %s", H::LDS_BYTES, hipGetErrorString(e));
+      return -2;
+    }
+    attr_done = true;
+  }
+  const int ntiles = 3 * (p.Cpad / CC) * p.tiles_n;
+  dim3 grid(ntiles, 1, zdim);
+  if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
+  set_last_kernel("gemm_hwgrad_kernel<%d, %d>", CC, BN);
+  const int rc = check_launch("gemm_hwgrad_kernel");
+  return rc ? rc : 1;
+}
+
+}  // namespace

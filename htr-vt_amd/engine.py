@@ -93,6 +93,7 @@ class Engine:
         # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
         # plus a residual round trip of the whole input gradient
         self.fuse_downsample_dgrad = True
+        self.halo_wgrad = True         # 3x3 stride-1 conv weight gradients on the halo-staged kernel (csrc/gemm_hwgrad_impl.h)
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: the float32
         # parity path is bitwise reproducible run to run (tests/test_determinism_gpu.py)
         self.deterministic = dtype == torch.float32
@@ -231,19 +232,33 @@ class Engine:
             gemm(dy, w, dx, dtype=self.dtype, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_layout=MNMAJOR, act=act, preact=preact)
         return dx
 
-    def _split_k(self, Mo, No, Kred, conv=False):
+    def _hwgrad_tiles(self, g):
+        """output tiles per pixel range of the halo-staged conv weight-gradient kernel (csrc/gemm_hwgrad.hip: 3x3, stride 1,
+        row length a multiple of 64), or None where the generic kernel serves the convolution"""
+        if self.dtype != torch.bfloat16 or not self.halo_wgrad:
+            return None
+        if (g.kh, g.kw, g.sh, g.sw, g.ph, g.pw) != (3, 3, 1, 1, 1, 1) or g.Wi % 64:
+            return None
+        cp = cpad(g.Ci, self.dtype)
+        cc = 128 if cp % 128 == 0 else 64
+        bn = 192 if (g.Co + 191) // 192 * 192 <= (g.Co + 127) // 128 * 128 else 128
+        return 3 * (cp // cc) * ((g.Co + bn - 1) // bn), 3 * cc, bn
+
+    def _split_k(self, Mo, No, Kred, conv=False, tiling=None):
         """split-K factor of a weight-gradient GEMM: fill the 256 CUs in whole rounds, but keep the float32
         atomic traffic (one full output tile per block, ~1.3 TB/s chip-wide) small against the MFMA time."""
         bm, bn = (256, 192) if self.dtype == torch.bfloat16 else (128, 128)
         if conv and self.dtype == torch.bfloat16 and No % 256 == 0:
             bn = 256      # gemm_dma.hip pick_bn(): conv weight gradients with N % 256 == 0 use 256x256 tiles
         tiles = ((Mo + bm - 1) // bm) * ((No + bn - 1) // bn)
+        if tiling is not None:
+            tiles, bm, bn = tiling
         flops = 2.0 * Mo * No * Kred
         best, best_t = 1, None
         # multiples of 8 let the kernel keep all tiles of one K range on one XCD (shared L2); small factors otherwise
-        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, 129, 8)):
+        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, 129, 8)) + ([10, 12, 14, 20, 28] if tiling is not None else []):
             if Kred // s < 512:
-                break
+                continue
             blocks = tiles * s
             rounds = (blocks + 255) // 256
             t = flops / 1.0e15 * (rounds * 256.0 / blocks) + blocks * bm * bn * 4 / 1.3e12
@@ -366,7 +381,7 @@ class Engine:
         M = g.B * g.Ho * g.Wo
         cpi = cpad(g.Ci, self.dtype)
         packed = self._zeros(g.taps, cpi, g.Co)
-        sk = self._split_k(g.taps * cpi, g.Co, M, conv=True)
+        sk = self._split_k(g.taps * cpi, g.Co, M, conv=True, tiling=self._hwgrad_tiles(g))
         gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
              a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
              split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, g.taps * cpi, g.Co))

@@ -247,3 +247,43 @@ def test_strided_dgrad_with_downsample_gradient_as_extra_tap(cfg, fused_epilogue
         xhat = (bnx - mean) * rstd
         assert torch.equal(got[0], want.reshape(-1, Ci).sum(0))
         assert torch.equal(got[1], (want * xhat).reshape(-1, Ci).sum(0))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# halo-staged weight gradient of the 3x3 stride-1 convolutions (csrc/gemm_hwgrad_impl.h) on integer data: atomics and
+# slabs, XCD-grouped and plain split factors, channel chunks of 128 and 64, 192- and 128-column tiles, ragged pixel ranges
+# --------------------------------------------------------------------------------------------------------------------
+HWGRAD = [  # B, H, W, Ci, Co, split_k
+    (2, 4, 256, 192, 192, 8),      # Cpad 192 -> chunks of 64, three of them; XCD-grouped split
+    (2, 3, 128, 384, 384, 3),      # chunks of 128, two N tiles, plain split
+    (1, 2, 256, 768, 768, 1),      # no split at all
+    (3, 2, 64, 96, 256, 5),        # Ci = 96 -> Cpad 128 with a quarter padding; Co = 256 -> 128-column tiles; W = 64
+    (2, 8, 192, 64, 64, 16),       # Ci = Co = 64: one chunk, half-empty 128-column tile
+]
+
+
+@pytest.mark.parametrize("cfg", HWGRAD)
+@pytest.mark.parametrize("slabs", [False, True])
+def test_halo_conv_wgrad_exact(cfg, slabs):
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co, split_k = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=70)
+    w = T._ints((Co, Ci, 3, 3), -1, 2, seed=71).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=1, padding=1)
+    dy = T._ints(tuple(y.shape), -2, 3, seed=72)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (1, 1), 1)
+    M = Bn * Hh * Ww
+    cpi = ops.cpad(Ci, BF)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    want = T._pack_fwd(w.grad, cpi).permute(1, 2, 0)            # [taps][Cpad][Co]
+    for tile in (13, 3):                                         # 13: halo kernel, 3: the generic MN-major gather
+        base = T._ints((9, cpi, Co), -5, 6, seed=73)
+        dwp = base.float().cuda()
+        ws = torch.empty(max(split_k, 1), 9 * cpi, Co, dtype=torch.float32, device="cuda") if (slabs and split_k > 1) else None
+        ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                 gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, splitk_ws=ws, tile=tile)
+        if tile == 13:
+            assert "gemm_hwgrad_kernel" in _last_kernel(), _last_kernel()
+        assert torch.equal(dwp.double().cpu(), base + want), (tile, float((dwp.double().cpu() - base - want).abs().max()))

@@ -122,12 +122,14 @@ def main():
         rows.append((tag + " dgrad", ms, fl))
         dw = torch.zeros(g.taps, Ci, Co, dtype=torch.float32, device=dev)
         from htrvt_amd.engine import Engine, ModelShape
-        split = Engine(ModelShape(80, (64, 1024), 768, 4, 6), dt)._split_k(g.taps * Ci, Co, M, conv=True)
+        eng_ = Engine(ModelShape(80, (64, 1024), 768, 4, 6), dt)
+        split_h = eng_._split_k(g.taps * Ci, Co, M, conv=True, tiling=eng_._hwgrad_tiles(g))    # halo-staged kernel's tiling
+        split = eng_._split_k(g.taps * Ci, Co, M, conv=True)                                     # generic kernel
         split = int(os.environ.get('HTRVT_BENCH_SPLITK', split))
         ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
-                                     b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci, split_k=split,
-                                     accumulate=True, c_f32=True), args.iters)
-        rows.append((tag + f" wgrad(split {split})", ms, fl))
+                                     b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci,
+                                     split_k=split_h if TILE in (0, 13) else split, accumulate=True, c_f32=True), args.iters)
+        rows.append((tag + f" wgrad(split {split_h}/{split})", ms, fl))
 
     if not args.only or "plain" in args.only:
         plain("NT 4096^3", 4096, 4096, 4096)

@@ -329,11 +329,11 @@ def main():
                    "avg_ms": round(av_, 4), "tflops": round(fl_ / (av_ * 1e-3) / 1e12, 1)} for _, k_, fl_, av_, n_ in sym["shapes"][:4]]
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch (mean over the symbol's launches) from the committed PMC passes of this round's build
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 pm = json.load(f)
             ent = pm["symbols"].get(symname)
             if ent is not None and B == 128 and args.width == 1024 and args.dtype == "bf16" and not args.forward_only:
-                traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r02_pmc_traffic.json"
+                traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r03_pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",

@@ -119,8 +119,9 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
         flops = 2.0 * M * N * (K // Cpad) * geom.Co
     else:   # algorithmic FLOPs of the convolution, whichever of fwd/dgrad/wgrad this launch is
         flops = 2.0 * geom.B * geom.Ho * geom.Wo * geom.Co * geom.taps * geom.Ci
-    key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1))
-    ent = PROFILE.setdefault(key, {"flops": flops, "events": [], "kernel": lib.htrvt_last_kernel().decode()})
+    kern = lib.htrvt_last_kernel().decode()     # in the key: a strided and a stride-1 conv can share (M, N, K) but not the kernel
+    key = (d.dtype, a_layout, b_layout, gather, M, N, K, max(batch, 1), kern)
+    ent = PROFILE.setdefault(key, {"flops": flops, "events": [], "kernel": kern})
     ent["events"].append((e0, e1))
     return d
 

@@ -19,6 +19,18 @@ GATHER_NONE, GATHER_CONV_FWD, GATHER_CONV_DGRAD, GATHER_CONV_WGRAD = 0, 1, 2, 3
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 
+class RelayoutJob(C.Structure):
+    """include/htrvt.h HtrvtRelayoutJob: one tensor of a table-driven re-layout launch (csrc/relayout.hip)"""
+    _fields_ = [
+        ("src", vp), ("dst0", vp), ("dst1", vp), ("kind", i32), ("d0", i32), ("d1", i32),
+        ("taps", i32), ("cpad_in", i32), ("cpad_out", i32), ("row_taps", i32), ("tap0", i32),
+        ("tile0", i32), ("tiles_x", i32), ("reserved_", i32 * 2),
+    ]
+
+
+RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS = 0, 1, 2, 64
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("a_layout", i32), ("b_layout", i32), ("gather", i32),
@@ -84,6 +96,8 @@ PROTOTYPES = {
     "htrvt_pack_conv_weight_slots": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "htrvt_relayout_plan": (i32, [vp, i32]),
+    "htrvt_relayout": (i32, [vp, i32, i32, i32, vp]),
     "htrvt_relpos_bias_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_relpos_bias_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_cast_transpose_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),

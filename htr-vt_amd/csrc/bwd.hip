@@ -677,84 +677,10 @@ __global__ __launch_bounds__(RS_NT) void rowsum_f32_kernel(const float* __restri
   out[c] += a;
 }
 
-// ------------------------------------------------------------------ weight packing / unpacking, cast, AdamW
-// One block = 16 output channels x 32 input channels x all taps, staged through LDS so that the float32 source rows
-// (contiguous [ci][tap] runs) and both packed destinations ([co][tap][ci] and [ci][tap][co]) move as contiguous runs.
-constexpr int PK_CO = 16, PK_CI = 32, PK_MAXT = 9;
-
-template <typename T>
-__global__ __launch_bounds__(NT) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd,
-                                                              T* __restrict__ dgr, int Co, int Ci, int taps, int cpi,
-                                                              int cpo, int row_taps, int tap0) {
-  __shared__ float tile[PK_CO][PK_CI * PK_MAXT + 1];
-  const int co0 = blockIdx.y * PK_CO, ci0 = blockIdx.x * PK_CI;
-  const int run = PK_CI * taps;
-  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
-    const int r = i / run, c = i - r * run;
-    float v = 0.f;
-    if (co0 + r < Co && ci0 + c / taps < Ci) v = w[((long long)(co0 + r) * Ci + ci0) * taps + c];
-    tile[r][c] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
-    const int r = i / run, rem = i - r * run;
-    const int t = rem / PK_CI, ci = rem - t * PK_CI;
-    if (fwd != nullptr && co0 + r < Co && ci0 + ci < Ci) fwd[((long long)(co0 + r) * taps + t) * cpi + ci0 + ci] = from_f32<T>(tile[r][ci * taps + t]);
-  }
-  if (dgr != nullptr) {
-    for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
-      const int ci = i / (taps * PK_CO), rem = i - ci * taps * PK_CO;
-      const int t = rem / PK_CO, r = rem - t * PK_CO;
-      if (co0 + r < Co && ci0 + ci < Ci) dgr[((long long)(ci0 + ci) * row_taps + tap0 + t) * cpo + co0 + r] = from_f32<T>(tile[r][ci * taps + t]);
-    }
-  }
-}
-
-// packed is the wgrad GEMM output [taps][cpi][Co]; grad [Co][Ci][taps] += its transpose (same tiling as the pack)
-__global__ __launch_bounds__(NT) void unpack_conv_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ grad,
-                                                               int Co, int Ci, int taps, int cpi) {
-  __shared__ float tile[PK_CO][PK_CI * PK_MAXT + 1];
-  const int co0 = blockIdx.y * PK_CO, ci0 = blockIdx.x * PK_CI;
-  const int run = PK_CI * taps;
-  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
-    const int ci = i / (taps * PK_CO), rem = i - ci * taps * PK_CO;
-    const int t = rem / PK_CO, r = rem - t * PK_CO;
-    float v = 0.f;
-    if (co0 + r < Co && ci0 + ci < Ci) v = packed[((long long)t * cpi + ci0 + ci) * Co + co0 + r];
-    tile[r][ci * taps + t] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < PK_CO * run; i += NT) {
-    const int r = i / run, c = i - r * run;
-    if (co0 + r < Co && ci0 + c / taps < Ci) grad[((long long)(co0 + r) * Ci + ci0) * taps + c] += tile[r][c];
-  }
-}
-
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     dst[i] = from_f32<T>(src[i]);
-}
-
-// dst[r][c] = src[r][c] (optional) and dst_t[c][r] = src[r][c], both rounded to T; dst_t rows are ld_t long, columns
-// rows .. ld_t-1 are zero filled.  64 x 64 tiles through LDS: 256-byte global reads, 128-byte global writes.
-template <typename T>
-__global__ __launch_bounds__(NT) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t,
-                                                            int rows, int cols, int ld_t) {
-  __shared__ float tile[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows of 64 threads
-  for (int rr = ty; rr < 64; rr += NT / 64) {
-    const int r = r0 + rr, c = c0 + tx;
-    const float v = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
-    tile[rr][tx] = v;
-    if (dst != nullptr && r < rows && c < cols) dst[(long long)r * cols + c] = from_f32<T>(v);
-  }
-  __syncthreads();
-  for (int cc = ty; cc < 64; cc += NT / 64) {
-    const int c = c0 + cc, r = r0 + tx;
-    if (c < cols && r < ld_t) dst_t[(long long)c * ld_t + r] = from_f32<T>(tile[tx][cc]);   // rows >= `rows` were read as 0
-  }
 }
 
 // decoupled weight decay Adam over one flat float32 buffer (torch.optim.AdamW semantics)
@@ -968,48 +894,11 @@ extern "C" int htrvt_conv1_wgrad(const void* img, const float* stats, const void
   return check_launch("conv1_wgrad");
 }
 
-extern "C" int htrvt_pack_conv_weight(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
-                                      int cpad_out, int dtype, void* stream) {
-  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT, "pack_conv_weight: taps=%d unsupported (1..%d)", taps, PK_MAXT);
-  dim3 grid((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
-                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out, taps, 0));
-  return check_launch("pack_conv_weight");
-}
-
-extern "C" int htrvt_pack_conv_weight_slots(const float* w, void* fwd, void* dgrad, int Co, int Ci, int taps, int cpad_in,
-                                            int cpad_out, int row_taps, int tap0, int dtype, void* stream) {
-  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT && tap0 >= 0 && tap0 + taps <= row_taps, "pack_conv_weight_slots: bad tap slots");
-  dim3 grid((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, w, (T*)fwd,
-                                       (T*)dgrad, Co, Ci, taps, cpad_in, cpad_out, row_taps, tap0));
-  return check_launch("pack_conv_weight_slots");
-}
-
-extern "C" int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in,
-                                       void* stream) {
-  HTRVT_REQUIRE(taps >= 1 && taps <= PK_MAXT, "unpack_conv_wgrad: taps=%d unsupported (1..%d)", taps, PK_MAXT);
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((Ci + PK_CI - 1) / PK_CI, (Co + PK_CO - 1) / PK_CO), dim3(NT), 0, (hipStream_t)stream, packed, grad, Co, Ci,
-                     taps, cpad_in);
-  return check_launch("unpack_conv_wgrad");
-}
-
 extern "C" int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
   HTRVT_REQUIRE(dtype == HTRVT_BF16, "htrvt_cast_f32: only float32 -> bfloat16");
   hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, src, (bf16_t*)dst,
                      (long long)n);
   return check_launch("cast_f32");
-}
-
-extern "C" int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows, int cols, int ld_t, int dtype,
-                                        void* stream) {
-  HTRVT_REQUIRE(dtype == HTRVT_BF16, "htrvt_cast_transpose_f32: only float32 -> bfloat16");
-  HTRVT_REQUIRE(src && dst_t && rows > 0 && cols > 0 && ld_t >= rows, "htrvt_cast_transpose_f32: bad arguments");
-  static_assert(NT == 256, "cast_transpose_kernel: 4 rows of 64 threads");
-  dim3 grid((cols + 63) / 64, (ld_t + 63) / 64);
-  hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(NT), 0, (hipStream_t)stream, src, (bf16_t*)dst, (bf16_t*)dst_t, rows,
-                     cols, ld_t);
-  return check_launch("cast_transpose_f32");
 }
 
 extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

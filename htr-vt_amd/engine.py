@@ -19,7 +19,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import lib, check
+from ._lib import lib, check, RelayoutJob, RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS
 from .ops import KMAJOR, MNMAJOR, GATHER_CONV_DGRAD, GATHER_CONV_FWD, GATHER_CONV_WGRAD, ConvGeom, cpad, dt, gemm, ptr, stream
 
 LN_EPS = 1e-6       # HTR_VT.py:252
@@ -64,6 +64,13 @@ class ModelShape:
         return names + ["head"]
 
 
+def _job(kind, src, dst0, dst1, d0, d1, taps=0, cpad_in=0, cpad_out=0, row_taps=0, tap0=0):
+    j = RelayoutJob()
+    j.src, j.dst0, j.dst1, j.kind, j.d0, j.d1 = ptr(src), ptr(dst0), ptr(dst1), kind, d0, d1
+    j.taps, j.cpad_in, j.cpad_out, j.row_taps, j.tap0 = taps, cpad_in, cpad_out, row_taps, tap0
+    return j
+
+
 class Engine:
     def __init__(self, shape: ModelShape, dtype=torch.float32, device="cuda"):
         self.s = shape
@@ -89,6 +96,10 @@ class Engine:
         # under the (HBM-bound) image statistics, conv1 and max-pool kernels, instead of ~30 latency-bound launches in
         # front of their first use
         self.prefetch_packs = True
+        # bf16: every conv / Linear weight is re-packed by ONE table-driven launch per step and the conv weight gradients are
+        # unpacked by one launch per DP bucket (csrc/relayout.hip) instead of one launch per tensor (47 per step)
+        self.table_relayout = True
+        self._rl_cache, self._pending_unpack = {}, []
         # first block of a stage, bf16: the input gradient of the 1x1 downsample conv is formed INSIDE the class-(0,0) launch
         # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
         # plus a residual round trip of the whole input gradient
@@ -385,7 +396,90 @@ class Engine:
         gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
              a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
              split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, g.taps * cpi, g.Co))
-        check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
+        if self.table_relayout and self._zoff is not None:    # inside backward(): unpacked with its DP bucket, one launch
+            self._pending_unpack.append((packed, dw, g.Co, g.Ci, g.taps, cpi))
+        else:
+            check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(dw), g.Co, g.Ci, g.taps, cpi, stream()), "unpack_conv_wgrad")
+
+    def _flush_unpacks(self):
+        """grad [Co][Ci][taps] += every pending conv weight-gradient GEMM output, one launch, on the stream that produced them"""
+        if not self._pending_unpack:
+            return
+        pend, self._pending_unpack = self._pending_unpack, []
+
+        def run():
+            self._relayout([_job(RELAYOUT_UNPACK_WGRAD, packed, dw, None, Co, Ci, taps, cpi) for packed, dw, Co, Ci, taps, cpi in pend])
+        self._on_side(run)
+
+    # ------------------------------------------------------------------ table-driven re-layouts (csrc/relayout.hip)
+    def _relayout(self, jobs):
+        """run RelayoutJobs, <= 64 per launch.  The planned table lives in device memory and is reused while the pointers
+        and sizes in it stay the same (flat parameter / gradient buffers and the pack buffers are persistent)."""
+        for i in range(0, len(jobs), RELAYOUT_MAX_JOBS):
+            chunk = jobs[i:i + RELAYOUT_MAX_JOBS]
+            arr = (RelayoutJob * len(chunk))(*chunk)
+            sig = bytes(arr)
+            ent = self._rl_cache.get(sig)
+            if ent is None:
+                total = lib.htrvt_relayout_plan(arr, len(chunk))
+                if total < 0:
+                    raise RuntimeError(lib.htrvt_last_error().decode())
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+                dev = host.to(self.dev, non_blocking=True)
+                torch.cuda.current_stream().synchronize()     # once per table: later launches may come from another stream
+                if len(self._rl_cache) >= 32:
+                    self._rl_cache.clear()
+                ent = self._rl_cache[sig] = (dev, total)
+            check(lib.htrvt_relayout(ptr(ent[0]), len(chunk), ent[1], self.dti, stream()), "relayout")
+
+    def _repack_all(self, P, save):
+        """bf16: refresh every stale conv pack / Linear copy in one launch (what _conv_w / _conv_w_joint_dgrad / _lin_w /
+        _head_w would do one tensor at a time on their first use after an optimizer step)."""
+        s = self.s
+        jobs, fresh = [], []
+        for name, _ci, _co, _k, _st, _pd in s.stem_convs():
+            w = P[name + ".weight"]
+            key, ent = self._wkey(w), self._packs.get(name)
+            if ent is not None and ent[0] == key:
+                continue
+            Co, Ci, kh, kw = w.shape
+            taps, cpi, cpo = kh * kw, cpad(Ci, self.dtype), cpad(Co, self.dtype)
+            bufs = ent[1] if ent is not None else (torch.zeros(Co, taps, cpi, dtype=self.dtype, device=self.dev),
+                                                   torch.zeros(Ci, taps, cpo, dtype=self.dtype, device=self.dev))
+            jobs.append(_job(RELAYOUT_PACK_CONV, w, bufs[0], bufs[1], Co, Ci, taps, cpi, cpo, taps, 0))
+            fresh.append((name, key, bufs))
+        if save and self.fuse_downsample_dgrad:
+            for li in (1, 2, 3):
+                pb = f"patch_embed.layer{li}.0"
+                w3, wd = P[pb + ".conv1.weight"], P[pb + ".downsample.0.weight"]
+                key, ent = (self._wkey(w3), self._wkey(wd)), self._packs.get(pb + ".conv1+ds")
+                if ent is not None and ent[0] == key:
+                    continue
+                Co, Ci, kh, kw = w3.shape
+                taps, cpi, cpo = kh * kw, cpad(Ci, self.dtype), cpad(Co, self.dtype)
+                buf = ent[1] if ent is not None else torch.zeros(Ci, taps + 1, cpo, dtype=self.dtype, device=self.dev)
+                jobs.append(_job(RELAYOUT_PACK_CONV, w3, None, buf, Co, Ci, taps, cpi, cpo, taps + 1, 0))
+                jobs.append(_job(RELAYOUT_PACK_CONV, wd, None, buf, Co, Ci, 1, cpi, cpo, taps + 1, taps))
+                fresh.append((pb + ".conv1+ds", key, buf))
+        for name in s.linears():
+            w = P[name + ".weight"]
+            key, ent = self._wkey(w), self._packs.get(name)
+            if ent is not None and ent[0] == key:
+                continue
+            out_f, in_f = w.shape
+            ld_t = (out_f + 7) // 8 * 8 if name == "head" else out_f     # head: classes zero-padded to a multiple of 8
+            if ent is not None:
+                bufs = ent[1]
+            elif name == "head":
+                bufs = (torch.zeros(ld_t, in_f, dtype=self.dtype, device=self.dev), torch.zeros(in_f, ld_t, dtype=self.dtype, device=self.dev))
+            else:
+                bufs = (self._empty(out_f, in_f), self._empty(in_f, out_f))
+            jobs.append(_job(RELAYOUT_CAST_TRANSPOSE, w, bufs[0], bufs[1], out_f, in_f, 0, ld_t))
+            fresh.append((name, key, bufs))
+        if jobs:
+            self._relayout(jobs)
+            for name, key, bufs in fresh:
+                self._packs[name] = (key, bufs)
 
     # ------------------------------------------------------------------ BatchNorm pieces
     def bn_coeffs(self, P, prefix, C, train, cs=None, rows=0, count=0, save=False):
@@ -505,17 +599,20 @@ class Engine:
                 self._side = torch.cuda.Stream(device=self.dev)
             self._side.wait_stream(torch.cuda.current_stream())     # behind whatever wrote the weights (the optimizer step)
             with torch.cuda.stream(self._side):
-                for name, _ci, _co, _k, _st, _pd in s.stem_convs():
-                    self._conv_w(name, P[name + ".weight"])
-                if save and self.fuse_downsample_dgrad:
-                    for li in (1, 2, 3):
-                        pb = f"patch_embed.layer{li}.0"
-                        self._conv_w_joint_dgrad(pb + ".conv1", P[pb + ".conv1.weight"], pb + ".downsample.0", P[pb + ".downsample.0.weight"])
-                for name in s.linears():
-                    if name == "head":
-                        self._head_w(P["head.weight"])
-                    else:
-                        self._lin_w(name, P[name + ".weight"])
+                if self.table_relayout:
+                    self._repack_all(P, save)
+                else:
+                    for name, _ci, _co, _k, _st, _pd in s.stem_convs():
+                        self._conv_w(name, P[name + ".weight"])
+                    if save and self.fuse_downsample_dgrad:
+                        for li in (1, 2, 3):
+                            pb = f"patch_embed.layer{li}.0"
+                            self._conv_w_joint_dgrad(pb + ".conv1", P[pb + ".conv1.weight"], pb + ".downsample.0", P[pb + ".downsample.0.weight"])
+                    for name in s.linears():
+                        if name == "head":
+                            self._head_w(P["head.weight"])
+                        else:
+                            self._lin_w(name, P[name + ".weight"])
             prefetched = True
 
         # --- whitening statistics + conv1 + BN + ReLU + maxpool (resnet18.py:74-77) ---
@@ -706,6 +803,7 @@ class Engine:
         scale = hd ** -0.5
         dy = dy.contiguous()
         self._zarena_begin()
+        self._pending_unpack = []
         self._bn_train = bool(sv["train"])
         assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
         self._side_active = self.overlap_wgrad
@@ -793,6 +891,7 @@ class Engine:
             p = blk["p"]
             C = blk["cb"].shape[-1]
             if bi == len(blocks) - 3 and after_layer3 is not None:   # both layer-3 blocks (78 % of the stem's weights) are done
+                self._flush_unpacks()
                 after_layer3(self._wgrad_stream())
             if parts is None:   # dout is an unmasked gradient: classic path (mask + sums in one reduction pass)
                 dcb, gm = self.bn_backward(dout, blk["out"], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3],
@@ -877,6 +976,7 @@ class Engine:
             partial = self._empty(nblk, C1 * 9, dtype=torch.float32)
             check(lib.htrvt_conv1_wgrad(ptr(img), ptr(sv["stats"]), ptr(dc1), ptr(G["patch_embed.conv1.weight"]), ptr(partial),
                                         B, 2 * Hh, W, C1, self.dti, u8, st), "conv1_wgrad")
+        self._flush_unpacks()
         self._join_side()
         self._side_active = False
         self._zarena_end()

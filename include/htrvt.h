@@ -261,6 +261,28 @@ int htrvt_pack_conv_weight_slots(const float* w, void* fwd, void* dgrad, int Co,
 /* grad [Co][Ci][taps] += packed [taps][cpad_in][Co]  (the conv-wgrad GEMM output) */
 int htrvt_unpack_conv_wgrad(const float* packed, float* grad, int Co, int Ci, int taps, int cpad_in, void* stream);
 int htrvt_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
+
+/* The same re-layouts as ONE launch over a table of jobs (csrc/relayout.hip): every conv / Linear weight of the model is
+ * re-packed once per optimizer step and every conv weight gradient unpacked once per backward -- 47 small launches per step
+ * as single-tensor calls.  Fill src / dst / kind / sizes, let htrvt_relayout_plan assign the workgroup ranges (host side),
+ * copy the table to the device, then htrvt_relayout(table_dev, njobs, total) runs all jobs.  A job's fields mean what the
+ * single-tensor entry point of its kind documents above / below. */
+#define HTRVT_RELAYOUT_PACK_CONV 0      /* src w [d0 = Co][d1 = Ci][taps] f32 -> dst0 fwd pack, dst1 dgrad pack (either may be NULL) */
+#define HTRVT_RELAYOUT_CAST_TRANSPOSE 1 /* src w [d0 = rows][d1 = cols] f32 -> dst0 [rows][cols] (may be NULL), dst1 [cols][cpad_in = ld_t] */
+#define HTRVT_RELAYOUT_UNPACK_WGRAD 2   /* src packed [taps][cpad_in][d0 = Co] f32, dst0 grad [Co][d1 = Ci][taps] f32 += */
+#define HTRVT_RELAYOUT_MAX_JOBS 64
+typedef struct HtrvtRelayoutJob {
+  const void* src;
+  void* dst0;
+  void* dst1;
+  int kind;
+  int d0, d1;
+  int taps, cpad_in, cpad_out, row_taps, tap0;
+  int tile0, tiles_x;     /* filled by htrvt_relayout_plan */
+  int reserved_[2];
+} HtrvtRelayoutJob;
+int htrvt_relayout_plan(HtrvtRelayoutJob* jobs_host, int njobs);   /* returns the launch's workgroup count, < 0 on a bad job */
+int htrvt_relayout(const HtrvtRelayoutJob* jobs_dev, int njobs, int total_tiles, int dtype, void* stream);
 /* Linear weight w [rows = out][cols = in] float32 -> dst [rows][cols] (may be NULL) and dst_t [cols][ld_t] = w^T in
  * `dtype` (bfloat16), columns rows .. ld_t-1 of dst_t zero: the K-major B operand of the Linear dgrad GEMM
  * dx[M][in] = dy[M][out] * w (HTR_VT.py:22-37 backward), so that forward and dgrad run the same kernel. */

@@ -13,7 +13,7 @@ def _lib():
     return lib, check, ptr, stream
 
 
-@pytest.mark.parametrize("Co,Ci,taps", [(192, 192, 9), (384, 192, 1), (40, 24, 9), (768, 384, 9)])
+@pytest.mark.parametrize("Co,Ci,taps", [(192, 192, 9), (384, 192, 1), (40, 24, 9), (768, 384, 9), (37, 21, 9), (33, 65, 4), (5, 3, 1)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_pack_and_unpack_conv_weight(Co, Ci, taps, dtype):
     lib, check, ptr, stream = _lib()
@@ -31,6 +31,68 @@ def test_pack_and_unpack_conv_weight(Co, Ci, taps, dtype):
     grad = w.clone()
     check(lib.htrvt_unpack_conv_wgrad(ptr(packed), ptr(grad), Co, Ci, taps, cpi, stream()), "unpack")
     assert torch.equal(grad, w + packed[:, :Ci, :].permute(2, 1, 0))
+
+
+def test_relayout_table_runs_every_job_of_a_launch():
+    """csrc/relayout.hip: conv packs (one of them into the tap slots of a joint buffer), Linear cast + transpose (one with
+    the head's padded leading dimension) and weight-gradient unpacks as ONE table-driven launch each, against torch."""
+    lib, check, ptr, stream = _lib()
+    import ctypes as C
+    from htrvt_amd._lib import RelayoutJob, RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD
+    from htrvt_amd.engine import _job
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    ints = lambda *shape: torch.randint(-64, 64, shape, generator=g).float().cuda()
+
+    def run(jobs, dti):
+        arr = (RelayoutJob * len(jobs))(*jobs)
+        total = lib.htrvt_relayout_plan(arr, len(jobs))
+        assert total > 0, lib.htrvt_last_error()
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        check(lib.htrvt_relayout(ptr(dev), len(jobs), total, dti, stream()), "relayout")
+        torch.cuda.synchronize()
+
+    convs = [(192, 64, 9), (40, 24, 9), (384, 192, 1), (37, 21, 9), (16, 8, 4)]
+    jobs, want = [], []
+    for Co, Ci, taps in convs:
+        w = ints(Co, Ci, taps)
+        cpi, cpo = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+        fwd = torch.zeros(Co, taps, cpi, dtype=bf, device="cuda")
+        dgr = torch.zeros(Ci, taps, cpo, dtype=bf, device="cuda")
+        jobs.append(_job(RELAYOUT_PACK_CONV, w, fwd, dgr, Co, Ci, taps, cpi, cpo, taps, 0))
+        want.append((w, fwd, dgr, Co, Ci))
+    # a 3x3 and a 1x1 weight sharing one [Ci][10][Co] dgrad buffer (HtrvtGemmDesc.A2)
+    w3, w1 = ints(48, 24, 9), ints(48, 24, 1)
+    joint = torch.zeros(24, 10, 48, dtype=bf, device="cuda")
+    jobs.append(_job(RELAYOUT_PACK_CONV, w3, None, joint, 48, 24, 9, 24, 48, 10, 0))
+    jobs.append(_job(RELAYOUT_PACK_CONV, w1, None, joint, 48, 24, 1, 24, 48, 10, 9))
+    lins = []
+    for rows, cols, ld in [(2304, 768, 2304), (80, 768, 80), (77, 100, 80)]:
+        w = ints(rows, cols)
+        d0 = torch.zeros(rows, cols, dtype=bf, device="cuda")
+        d1 = torch.full((cols, ld), 7.0, dtype=bf, device="cuda")
+        jobs.append(_job(RELAYOUT_CAST_TRANSPOSE, w, d0, d1, rows, cols, 0, ld))
+        lins.append((w, d0, d1, rows))
+    run(jobs, 1)
+    for w, fwd, dgr, Co, Ci in want:
+        assert torch.equal(fwd[:, :, :Ci].float(), w.permute(0, 2, 1)) and torch.equal(dgr[:, :, :Co].float(), w.permute(1, 2, 0))
+        assert (fwd[:, :, Ci:] == 0).all() and (dgr[:, :, Co:] == 0).all()
+    assert torch.equal(joint[:, :9].float(), w3.permute(1, 2, 0)) and torch.equal(joint[:, 9].float(), w1[:, :, 0].t())
+    for w, d0, d1, rows in lins:
+        assert torch.equal(d0.float(), w) and torch.equal(d1[:, :rows].float(), w.t()) and (d1[:, rows:] == 0).all()
+    # unpack: grad += packed^T for all convs in one launch
+    jobs, want = [], []
+    for Co, Ci, taps in convs:
+        cpi = (Ci + 7) // 8 * 8
+        packed, grad = ints(taps, cpi, Co), ints(Co, Ci, taps)
+        want.append((grad.clone() + packed[:, :Ci, :].permute(2, 1, 0), grad, packed))
+        jobs.append(_job(RELAYOUT_UNPACK_WGRAD, packed, grad, None, Co, Ci, taps, cpi))
+    run(jobs, 1)
+    for w_, got, _ in want:
+        assert torch.equal(got, w_)
+    # a malformed job is refused by the plan, not launched
+    bad = (RelayoutJob * 1)(_job(RELAYOUT_PACK_CONV, w3, None, joint, 48, 24, 9, 24, 48, 9, 1))     # tap slots 1..9 of 9
+    assert lib.htrvt_relayout_plan(bad, 1) < 0
 
 
 @pytest.mark.parametrize("rows,cols,ld", [(32768, 768, 768), (1000, 80, 88), (37, 3072, 3072), (4096, 2304, 2304)])

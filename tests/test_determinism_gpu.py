@@ -59,6 +59,29 @@ def test_f32_training_iterations_bitwise_reproducible(shape):
         assert torch.equal(s1[k], s2[k]), k
 
 
+def test_table_relayout_equals_per_tensor_relayout_bf16():
+    """bf16 engine: the one-launch weight re-pack / gradient unpack (csrc/relayout.hip, Engine.table_relayout) against the
+    per-tensor launches, two AdamW steps each with slab split-K: every gradient and parameter bit-identical"""
+    from htrvt_amd.trainer import Trainer
+    cfg = O.Config(80, (64, 512), embed_dim=256, depth=4, num_heads=4)
+    x, targets, lengths = O.synthetic_batch(8, cfg.H, cfg.W, cfg.nb_cls, cfg.num_patches, seed=3)
+    outs = []
+    for table in (True, False):
+        _, m = _build(cfg, 7, dtype=torch.bfloat16)
+        tr = Trainer(m, max_lr=1e-3, betas=(0.9, 0.99), weight_decay=0.5)
+        tr.engine.deterministic = True
+        tr.engine.table_relayout = table
+        for it in range(2):
+            torch.manual_seed(50 + it)
+            mask = m.generate_span_mask(cfg.num_patches, 0.4, 8)
+            loss = tr.step(x.cuda(), targets, lengths, mask, lr=1e-3)
+        torch.cuda.synchronize()
+        outs.append((float(loss), tr.flat.flat_g.clone(), tr.flat.flat_p.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]), int((outs[0][1] != outs[1][1]).sum())
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_ctc_gradient_bitwise_reproducible():
     from htrvt_amd.ctc import ctc_forward_backward
     rng = np.random.default_rng(2)

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "htrvt_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "htrvt_bn_bwd_finalize": (i32, [vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "htrvt_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "htrvt_bn_bwd_apply2": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "htrvt_maxpool_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_conv1_bwd_rows": (i32, [i32, i32]),

@@ -354,6 +354,45 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   }
 }
 
+// pass B for the two BatchNorms that consume the SAME gradient (a stage's first block: bn2 of the main branch and the
+// downsample BN both receive the masked gradient of the block output, resnet18.py:33-37): g is read once,
+// dx1 = c1A*g + c1B*x1 + c1C and dx2 = c2A*g + c2B*x2 + c2C.  5 streams instead of 6.
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply2_kernel(const T* __restrict__ g, const T* __restrict__ x1, const float* __restrict__ coef1,
+                                                           T* __restrict__ dx1, const T* __restrict__ x2, const float* __restrict__ coef2,
+                                                           T* __restrict__ dx2, long long nvec, int C) {
+  constexpr int CH = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sco[];   // [2][3][C]
+  for (int k = threadIdx.x; k < 3 * C; k += NT) {
+    sco[k] = coef1[k];
+    sco[3 * C + k] = coef2[k];
+  }
+  __syncthreads();
+  const int cvec = C / CH;
+  const long long stride = (long long)gridDim.x * NT;
+  const int step = (int)(stride % cvec);
+  long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  int cv = (int)(i % cvec);
+  for (; i < nvec; i += stride) {
+    const float* ca = sco + cv * CH;
+    const float* cb = ca + 3 * C;
+    Vec16<T> vg, v1, v2, o1, o2;
+    vg.raw = reinterpret_cast<const decltype(vg.raw)*>(g)[i];
+    v1.raw = reinterpret_cast<const decltype(v1.raw)*>(x1)[i];
+    v2.raw = reinterpret_cast<const decltype(v2.raw)*>(x2)[i];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float gg = vg.get(j);
+      o1.set(j, fmaf(ca[j], gg, fmaf(ca[C + j], v1.get(j), ca[2 * C + j])));
+      o2.set(j, fmaf(cb[j], gg, fmaf(cb[C + j], v2.get(j), cb[2 * C + j])));
+    }
+    reinterpret_cast<decltype(o1.raw)*>(dx1)[i] = o1.raw;
+    reinterpret_cast<decltype(o2.raw)*>(dx2)[i] = o2.raw;
+    cv += step;
+    if (cv >= cvec) cv -= cvec;
+  }
+}
+
 // ------------------------------------------------------------------ first max-pool backward (index based) + ReLU mask
 // g[b,hi,wi,c] = (x*scale+shift > 0) * sum_{windows (ho,wo) containing (hi,wi) with idx == position} dpool[b,ho,wo,c]
 // One thread per (image, column, channel vector) marches down the input rows; a pooled row (gradient + arg-max
@@ -842,6 +881,18 @@ extern "C" int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* 
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(NT), (size_t)3 * C * sizeof(float), (hipStream_t)stream, (const T*)dy,
                                        (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
   return check_launch("bn_bwd_apply");
+}
+
+extern "C" int htrvt_bn_bwd_apply2(const void* g, const void* x1, const float* coef1, void* dx1, const void* x2,
+                                   const float* coef2, void* dx2, int64_t npix, int C, int dtype, void* stream) {
+  const int ch = dtype == HTRVT_BF16 ? 8 : 4;
+  HTRVT_REQUIRE(C % ch == 0 && C <= 2048, "htrvt_bn_bwd_apply2: C=%d unsupported", C);
+  HTRVT_REQUIRE(g && x1 && x2 && coef1 && coef2 && dx1 && dx2, "htrvt_bn_bwd_apply2: null buffer");
+  const long long nvec = npix * (C / ch);
+  dim3 grid(grid_for(nvec));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply2_kernel<T>, grid, dim3(NT), (size_t)6 * C * sizeof(float), (hipStream_t)stream, (const T*)g,
+                                       (const T*)x1, coef1, (T*)dx1, (const T*)x2, coef2, (T*)dx2, nvec, C));
+  return check_launch("bn_bwd_apply2");
 }
 
 extern "C" int htrvt_maxpool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* scale,

@@ -99,6 +99,7 @@ class Engine:
         # bf16: every conv / Linear weight is re-packed by ONE table-driven launch per step and the conv weight gradients are
         # unpacked by one launch per DP bucket (csrc/relayout.hip) instead of one launch per tensor (47 per step)
         self.table_relayout = True
+        self.merge_bn_backward = True   # first block of a stage: bn2 + downsample-BN backward in one pass over the shared gradient
         self._rl_cache, self._pending_unpack = {}, []
         # first block of a stage, bf16: the input gradient of the 1x1 downsample conv is formed INSIDE the class-(0,0) launch
         # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
@@ -518,9 +519,9 @@ class Engine:
                                       stream()), "bn_bwd_reduce")
         return self.bn_backward_finish(partial, nblk, dy, yact, x, prefix, P, G, mean, rstd, want_g, out=out)
 
-    def bn_backward_finish(self, partial, rows, g, yact, x, prefix, P, G, mean, rstd, want_g=False, out=None):
-        """finalize (dgamma, dbeta, coefficients) from per-tile partial sums, then dx = cA*g + cB*x + cC.
-        With yact=None, g is the already ReLU-masked gradient (fused dgrad epilogue)."""
+    def bn_backward_coef(self, partial, rows, x, prefix, P, G, mean, rstd):
+        """finalize dgamma / dbeta (accumulated into G) and the [3][C] coefficients of dx = cA*g + cB*x + cC from per-tile
+        partial sums"""
         C = x.shape[-1]
         npix = x.numel() // C
         coef = self._empty(3, C, dtype=torch.float32)
@@ -533,6 +534,14 @@ class Engine:
         check(lib.htrvt_bn_bwd_finalize(ptr(src), rows, C, count, ptr(P[prefix + ".weight"]), ptr(mean), ptr(rstd),
                                         ptr(G[prefix + ".weight"]), ptr(G[prefix + ".bias"]), ptr(coef), stream()),
               "bn_bwd_finalize")
+        return coef
+
+    def bn_backward_finish(self, partial, rows, g, yact, x, prefix, P, G, mean, rstd, want_g=False, out=None):
+        """finalize (dgamma, dbeta, coefficients) from per-tile partial sums, then dx = cA*g + cB*x + cC.
+        With yact=None, g is the already ReLU-masked gradient (fused dgrad epilogue)."""
+        C = x.shape[-1]
+        npix = x.numel() // C
+        coef = self.bn_backward_coef(partial, rows, x, prefix, P, G, mean, rstd)
         dx = torch.empty_like(x) if out is None else out
         gout = torch.empty_like(x) if want_g else None
         check(lib.htrvt_bn_bwd_apply(ptr(g), ptr(yact), ptr(x), ptr(coef), ptr(dx), ptr(gout), npix, C, self.dti, stream()),
@@ -899,16 +908,27 @@ class Engine:
                 parts_d = None
             else:               # dout is already g = dOut * (out > 0) and the sums exist
                 gm = dout
-                dcb, _ = self.bn_backward_finish(parts[0][0], parts[0][1], gm, None, blk["cb"], p + ".bn2", P, G,
-                                                 blk["bn_b"][2], blk["bn_b"][3])
                 parts_d = parts[1] if len(parts) > 1 else None
-            _, wd2 = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
-            self.conv_wgrad(dcb, blk["a1"], blk["g2"], G[p + ".conv2.weight"])
             # downsample gradient as one more tap of the strided conv's class-(0,0) dgrad: d(conv1 out) and d(downsample
             # out) then live back to back in one allocation (the second gather source sits at a fixed offset from the first)
             fuse_ds = self.fuse_downsample_dgrad and blk["gd"] is not None and self._dgrad_by_class(blk["g1"])
             pair = self._empty(2, *blk["ca"].shape) if fuse_ds else None
             dca_out = pair[0] if fuse_ds else None
+            dcd = None
+            if parts is not None:
+                if parts_d is not None and self.merge_bn_backward:
+                    # bn2 and the downsample BN take the same gradient: one pass, gm read once (csrc/bwd.hip bn_bwd_apply2)
+                    co_b = self.bn_backward_coef(parts[0][0], parts[0][1], blk["cb"], p + ".bn2", P, G, blk["bn_b"][2], blk["bn_b"][3])
+                    co_d = self.bn_backward_coef(parts_d[0], parts_d[1], blk["cd"], p + ".downsample.1", P, G, blk["bn_d"][2], blk["bn_d"][3])
+                    dcb = torch.empty_like(blk["cb"])
+                    dcd = pair[1] if fuse_ds else torch.empty_like(blk["cd"])
+                    check(lib.htrvt_bn_bwd_apply2(ptr(gm), ptr(blk["cb"]), ptr(co_b), ptr(dcb), ptr(blk["cd"]), ptr(co_d), ptr(dcd),
+                                                  dcb.numel() // C, C, self.dti, stream()), "bn_bwd_apply2")
+                else:
+                    dcb, _ = self.bn_backward_finish(parts[0][0], parts[0][1], gm, None, blk["cb"], p + ".bn2", P, G,
+                                                     blk["bn_b"][2], blk["bn_b"][3])
+            _, wd2 = self._conv_w(p + ".conv2", P[p + ".conv2.weight"])
+            self.conv_wgrad(dcb, blk["a1"], blk["g2"], G[p + ".conv2.weight"])
             if can_fuse(blk["g2"]):
                 rows1 = self.dgrad_tiles(blk["g2"])
                 part1 = self._empty(rows1, 2, C, dtype=torch.float32)
@@ -936,7 +956,9 @@ class Engine:
                 parts = [(b_, rows) for b_ in bufs]
             if blk["gd"] is not None:
                 dcd_out = pair[1] if fuse_ds else None
-                if parts_d is not None:
+                if dcd is not None:
+                    pass                      # came out of the joint pass with bn2 above
+                elif parts_d is not None:
                     dcd, _ = self.bn_backward_finish(parts_d[0], parts_d[1], gm, None, blk["cd"], p + ".downsample.1", P, G,
                                                      blk["bn_d"][2], blk["bn_d"][3], out=dcd_out)
                 else:

@@ -216,6 +216,10 @@ int htrvt_bn_bwd_finalize(const float* partial, int rows, int C, float count, co
                           const float* rstd, float* dgamma, float* dbeta, float* coef /* [3][C] */, void* stream);
 int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* x, const float* coef, void* dx, void* gout,
                        int64_t npix, int C, int dtype, void* stream);
+/* two BatchNorms fed by the same (already masked) gradient g -- bn2 and the downsample BN of a stage's first block,
+ * resnet18.py:33-37: dx1 = BN1-backward(g, x1), dx2 = BN2-backward(g, x2) with one read of g */
+int htrvt_bn_bwd_apply2(const void* g, const void* x1, const float* coef1, void* dx1, const void* x2, const float* coef2,
+                        void* dx2, int64_t npix, int C, int dtype, void* stream);
 /* backward of htrvt_bn_relu_maxpool: g = d(bn output, ReLU-masked), x = raw conv output [B,H,W,C] */
 int htrvt_maxpool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* scale, const float* shift,
                       void* g, int B, int H, int W, int C, int dtype, void* stream);

@@ -59,18 +59,21 @@ def test_f32_training_iterations_bitwise_reproducible(shape):
         assert torch.equal(s1[k], s2[k]), k
 
 
-def test_table_relayout_equals_per_tensor_relayout_bf16():
-    """bf16 engine: the one-launch weight re-pack / gradient unpack (csrc/relayout.hip, Engine.table_relayout) against the
-    per-tensor launches, two AdamW steps each with slab split-K: every gradient and parameter bit-identical"""
+@pytest.mark.parametrize("flag", ["table_relayout", "merge_bn_backward"])
+def test_launch_merges_are_bit_neutral_bf16(flag):
+    """bf16 engine, two AdamW steps with slab split-K, every gradient and parameter bit-identical with and without
+    * table_relayout: the one-launch weight re-pack / gradient unpack (csrc/relayout.hip) against per-tensor launches,
+    * merge_bn_backward: bn2 + downsample-BN backward of a stage's first block in one pass over the shared gradient."""
     from htrvt_amd.trainer import Trainer
     cfg = O.Config(80, (64, 512), embed_dim=256, depth=4, num_heads=4)
     x, targets, lengths = O.synthetic_batch(8, cfg.H, cfg.W, cfg.nb_cls, cfg.num_patches, seed=3)
     outs = []
-    for table in (True, False):
+    for on in (True, False):
         _, m = _build(cfg, 7, dtype=torch.bfloat16)
         tr = Trainer(m, max_lr=1e-3, betas=(0.9, 0.99), weight_decay=0.5)
         tr.engine.deterministic = True
-        tr.engine.table_relayout = table
+        assert getattr(tr.engine, flag) is True          # the default is the merged form
+        setattr(tr.engine, flag, on)
         for it in range(2):
             torch.manual_seed(50 + it)
             mask = m.generate_span_mask(cfg.num_patches, 0.4, 8)

@@ -617,7 +617,11 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
           float xp[CW];
           unpack(r, S_PRE, y, xp);
 #pragma unroll
-          for (int e = 0; e < CW; ++e) v[e] *= gelu_erf_grad_fast(xp[e]);
+          for (int e = 0; e < CW; e += 2) {
+            const f32x2_t gg = gelu_erf_grad_fast2(f32x2_t{xp[e], xp[e + 1]});
+            v[e] *= gg.x;
+            v[e + 1] *= gg.y;
+          }
         }
         if constexpr (EPI & E_GELU) {
           // the saved pre-activation is the bf16-rounded value and GELU is taken of that rounded value, so that the
@@ -626,8 +630,9 @@ __device__ __forceinline__ void gemm8p_body(const P& p, const int block_x) {
 #pragma unroll
           for (int e = 0; e < CW; e += 2) {
             const unsigned w = pack_bf16x2(v[e], v[e + 1]);
-            v[e] = gelu_erf_fast(__uint_as_float(w << 16));
-            v[e + 1] = gelu_erf_fast(__uint_as_float(w & 0xffff0000u));
+            const f32x2_t gg = gelu_erf_fast2(f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
+            v[e] = gg.x;
+            v[e + 1] = gg.y;
           }
         }
         if constexpr (EPI & E_RES) {

@@ -496,13 +496,21 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
           const float x[8] = {bf16lo(pr.x), bf16hi(pr.x), bf16lo(pr.y), bf16hi(pr.y),
                               bf16lo(pr.z), bf16hi(pr.z), bf16lo(pr.w), bf16hi(pr.w)};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad_fast(x[e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2_t gg = gelu_erf_grad_fast2(f32x2_t{x[e], x[e + 1]});
+            v[e] *= gg.x;
+            v[e + 1] *= gg.y;
+          }
         } else if (has_pre_out) {
           if (ok[u]) *reinterpret_cast<uint4*>(preb + o[u]) = raw[u];
         }
         if (has_gelu) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2_t gg = gelu_erf_fast2(f32x2_t{v[e], v[e + 1]});
+            v[e] = gg.x;
+            v[e + 1] = gg.y;
+          }
         }
         if (has_res) {
           const uint4 rr = rres[u];

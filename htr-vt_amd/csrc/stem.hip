@@ -7,9 +7,23 @@
 
 using namespace htrvt;
 
+namespace htrvt {
+int stem_mfma_try_launch(const void* img, const float* stats, const float* w, const float* scale, const float* shift, void* y,
+                         uint8_t* idx, int B, int H, int W, int C, int img_u8, hipStream_t st);
+}
+
 namespace {
 
 constexpr int NT = 256;
+
+// HTRVT_STEM_VALU=1: keep the float32-FMA stem kernel on the bfloat16 path too (A/B runs, tests of that kernel)
+bool stem_force_valu() {
+  static const bool v = [] {
+    const char* e = getenv("HTRVT_STEM_VALU");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
 
 // ------------------------------------------------------------------ img_stats
 // one block of 1024 threads per image; two passes (mean, then centred variance) -> {mean, rstd}; four 16-byte loads in
@@ -786,6 +800,10 @@ extern "C" int htrvt_stem_fwd(const void* img, const float* stats, const float* 
   HTRVT_REQUIRE(img && stats && w && scale && shift && y, "htrvt_stem_fwd: null argument");
   HTRVT_REQUIRE(C % ch == 0 && C / ch <= NT && H % 2 == 0 && H >= 4, "htrvt_stem_fwd: C=%d must be a multiple of %d and <= %d", C,
                 ch, NT * ch);
+  if (dtype == HTRVT_BF16 && !stem_force_valu()) {   // conv1 as an MFMA product, pooling in the accumulator layout (stem_mfma.hip)
+    const int r = stem_mfma_try_launch(img, stats, w, scale, shift, y, idx, B, H, W, C, img_u8, (hipStream_t)stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   const int lanes = C / ch, nthr = (NT / lanes) * lanes;
   const size_t smem = (size_t)7 * (W + 2) * 4;
   HTRVT_REQUIRE(smem <= 160 * 1024, "htrvt_stem_fwd: W=%d too wide for the LDS row buffer", W);

@@ -78,6 +78,39 @@ def test_fused_stem_against_the_float64_oracle():
     assert (got["a"].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("W,D,u8", [(576, 256, False), (1024, 768, True), (64, 128, False)])
+def test_mfma_stem_against_the_float64_oracle(W, D, u8):
+    """bf16 path, C1 = D/4 a multiple of 32: conv1 runs as a float16 MFMA product with the pooling done in the accumulator
+    layout (csrc/stem_mfma.hip).  Against the oracle's float64 conv1 -> BN(train) -> ReLU -> max_pool2d: values within a
+    bf16 ulp of the largest activation, arg-max bytes equal wherever the float64 window maximum is not a near tie."""
+    import torch.nn.functional as F
+    cfg = O.Config(80, (64, W), embed_dim=D, depth=1, num_heads=4)
+    sd = O.init_state_dict(cfg, seed=11, randomize_affine=True)
+    x = torch.rand(2, 1, 64, W, generator=torch.Generator().manual_seed(W))
+    if u8:
+        x = (x * 255).round().to(torch.uint8)
+    got = _stem(cfg, sd, x.cuda(), torch.bfloat16, fused=True)
+    xd = (x.double() / 255.0) if u8 else x.double()
+    xw = F.layer_norm(xd, xd.shape[1:], eps=1e-5)
+    y = F.conv2d(xw, sd["patch_embed.conv1.weight"].double(), stride=(2, 1), padding=1)
+    y = F.batch_norm(y, None, None, sd["patch_embed.bn1.weight"].double(), sd["patch_embed.bn1.bias"].double(), True, 0.1, 1e-5)
+    ref, ridx = F.max_pool2d(F.relu(y), 3, stride=(2, 1), padding=1, return_indices=True)
+    ref = ref.permute(0, 2, 3, 1)
+    a = got["a"].double()
+    assert a.shape == ref.shape
+    assert (a - ref).abs().max().item() < 2.0 ** -7 * ref.abs().max().item(), (a - ref).abs().max().item()
+    # arg-max byte = 3 * window row + window column (15: closed ReLU); compare where the oracle's maximum is open
+    Hc = y.shape[2]
+    rr, cc = ridx // W, ridx % W                                 # conv row / column of the arg-max
+    ph = torch.arange(ref.shape[1]).view(1, 1, -1, 1)
+    pw = torch.arange(W).view(1, 1, 1, -1)
+    want = (3 * (rr - (2 * ph - 1)) + (cc - (pw - 1))).permute(0, 2, 3, 1)
+    open_ = ref > 1e-2 * ref.abs().max()
+    same = (got["idx"].long()[open_] == want[open_]).float().mean().item()
+    assert same > 0.97, same
+    assert (got["idx"][ref == 0] == 15).float().mean().item() > 0.97
+
+
 def test_fused_stem_eval_mode_uses_running_statistics():
     cfg = O.Config(80, (64, 512), embed_dim=64, depth=1, num_heads=2)
     sd = O.init_state_dict(cfg, seed=5, randomize_affine=True)

@@ -72,10 +72,15 @@ __global__ __launch_bounds__(SM_NT) void stem_mfma_fwd_kernel(const void* __rest
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
-  // conv row k of this pooled row = conv row 2 ph - 1 + k; rows outside the conv output are pooling padding
-  bool rowok[3];
+  // conv row k of this pooled row = conv row 2 ph - 1 + k; a row outside the conv output is pooling padding: its keys are
+  // forced to 0 through the (block-uniform) mask and code of the v_and_or that builds them
+  unsigned kmask[3], kcode[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) rowok[k] = (2 * ph - 1 + k) >= 0 && (2 * ph - 1 + k) < Hc;
+  for (int k = 0; k < 3; ++k) {
+    const bool ok = (2 * ph - 1 + k) >= 0 && (2 * ph - 1 + k) < Hc;
+    kmask[k] = ok ? ~0xFu : 0u;
+    kcode[k] = ok ? (unsigned)(6 - 3 * k) : 0u;
+  }
   const f32x16_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int j = wave; j < nblk; j += SM_NT / 64) {
     const int p = SM_PIX * j - 1 + n;            // this lane's pixel (B column n); outputs are the lanes n = 1 .. 30
@@ -98,33 +103,41 @@ __global__ __launch_bounds__(SM_NT) void stem_mfma_fwd_kernel(const void* __rest
       bfr[k] = v;
     }
     const bool inside = p >= 0 && p < W;
+    const bool edge = j == 0 || j == nblk - 1;    // only these blocks hold columns outside the image (wave-uniform)
     const bool store_ok = n >= 1 && n <= SM_PIX && p < W;
     const long long pix = (long long)blockIdx.x * W + p;
     for (int cb = 0; cb < ncb; ++cb) {
       const f16x8_t a = afr[cb * 64 + lane];
+      const f32x16_t acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[0], zero, 0, 0, 0);
+      const f32x16_t acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[1], zero, 0, 0, 0);
+      const f32x16_t acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[2], zero, 0, 0, 0);
       int m[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m[r] = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (!rowok[k]) continue;      // block-uniform
-        const f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[k], zero, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[r] = max(m[r], (int)((__float_as_uint(acc[r]) & ~0xFu) | (unsigned)(6 - 3 * k)));
+      for (int r = 0; r < 16; ++r) {
+        const int k0 = (int)((__float_as_uint(acc0[r]) & kmask[0]) | kcode[0]);
+        const int k1 = (int)((__float_as_uint(acc1[r]) & kmask[1]) | kcode[1]);
+        const int k2 = (int)((__float_as_uint(acc2[r]) & kmask[2]) | kcode[2]);
+        m[r] = max(max(k0, k1), k2);
       }
+      if (edge) {                                   // columns outside the image are pooling padding
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = inside ? m[r] : 0;
+      }
+      // Negative keys (closed ReLU) are NOT clamped here: among negative candidates the integer maximum picks an arbitrary
+      // one, but any positive candidate beats them all and an all-negative window is closed either way.
       unsigned yv[8], iv[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         float o2[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int mm = inside ? m[r + e] : 0;      // columns outside the image are pooling padding
-          const int left = __builtin_amdgcn_update_dpp(0, mm + 2, 0x138, 0xf, 0xf, false);     // wave_shr:1: lane <- lane - 1
-          const int right = __builtin_amdgcn_update_dpp(0, mm, 0x130, 0xf, 0xf, false);        // wave_shl:1: lane <- lane + 1
-          const unsigned best = (unsigned)max(max(left, mm + 1), right);
-          const float mv = __uint_as_float(best & ~0xFu);
-          o2[e] = mv;
-          const unsigned am = mv > 0.f ? 8u - (best & 15u) : 15u;
+          const int mm = m[r + e];
+          const int left = __builtin_amdgcn_mov_dpp(mm + 2, 0x138, 0xf, 0xf, true);     // wave_shr:1: lane <- lane - 1
+          const int right = __builtin_amdgcn_mov_dpp(mm, 0x130, 0xf, 0xf, true);        // wave_shl:1: lane <- lane + 1
+          const int best = max(max(left, mm + 1), right);
+          const bool open = best > 15;                                                  // a positive value under the code bits
+          o2[e] = open ? __uint_as_float((unsigned)best & ~0xFu) : 0.f;
+          const unsigned am = open ? 8u - ((unsigned)best & 15u) : 15u;
           iv[(r + e) >> 2] |= am << (8 * ((r + e) & 3));
         }
         yv[r >> 1] = pack_bf16x2(o2[0], o2[1]);

@@ -12,7 +12,9 @@
 //   11-bit mantissas against the 8 of the bfloat16 result; the whitened pixels (|x| < ~10) and scaled weights are in range.
 // One MFMA = 32 channels x 32 pixels of ONE conv row.  MFMA row i carries channel 16*((i>>2)&1) + (i&3) + 4*(i>>3) of its
 // block of 32, which makes the 16 accumulator registers of a lane 16 CONSECUTIVE channels of one pixel: the pooled row is
-// stored straight from registers, 32 B of values + 16 B of arg-max bytes per lane and channel block, no LDS staging.
+// leaves the registers as 32 B of values + 16 B of arg-max bytes per lane and channel block; two channel blocks are
+// gathered in a per-wave LDS stage so that the global stores are 128 B / 64 B runs per pixel (16 B pieces per lane kept the
+// L2 request queues at two thirds of their rate: 419 us).
 // Pooling in the accumulator layout: the three conv rows of a pooled row are three accumulator sets of the same lane
 // (integer max of keys); the three columns are the neighbouring lanes (DPP wave_shr:1 / wave_shl:1).  A 32-pixel block
 // produces the 30 inner pixels (blocks overlap by two columns: no carry between blocks, 6.7 % redundant MFMA work).
@@ -29,6 +31,8 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int SM_NT = 256, SM_PIX = 30;
+constexpr int SM_YROW = 144, SM_IROW = 80;                      // staged row pitch in bytes: 128 + 16, 64 + 16
+constexpr int SM_STAGE = 32 * SM_YROW + 32 * SM_IROW;           // per wave
 
 __device__ __forceinline__ float pixel_of(const void* img, long long i, int u8) {
   return u8 ? (float)reinterpret_cast<const unsigned char*>(img)[i] / 255.0f : reinterpret_cast<const float*>(img)[i];
@@ -42,6 +46,9 @@ __global__ __launch_bounds__(SM_NT) void stem_mfma_fwd_kernel(const void* __rest
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   _Float16* rows = reinterpret_cast<_Float16*>(smem_raw);                       // [7][RS]: LDS column = image column + 2
   f16x8_t* afr = reinterpret_cast<f16x8_t*>(smem_raw + ((7 * RS * 2 + 15) & ~15));   // [C / 32][64] A fragments
+  // per-wave staging of two channel blocks (64 channels) of a 32-pixel block, so that the global stores are 128 B (values)
+  // and 64 B (arg-max bytes) runs per pixel instead of 16 B pieces per lane: padded rows, conflict-free b128 accesses
+  char* stage = reinterpret_cast<char*>(afr + (C / 32) * 64) + (threadIdx.x >> 6) * SM_STAGE;
   const int Hc = H / 2, Hp = (Hc - 1) / 2 + 1;
   const int b = blockIdx.x / Hp, ph = blockIdx.x - b * Hp;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
@@ -104,8 +111,6 @@ __global__ __launch_bounds__(SM_NT) void stem_mfma_fwd_kernel(const void* __rest
     }
     const bool inside = p >= 0 && p < W;
     const bool edge = j == 0 || j == nblk - 1;    // only these blocks hold columns outside the image (wave-uniform)
-    const bool store_ok = n >= 1 && n <= SM_PIX && p < W;
-    const long long pix = (long long)blockIdx.x * W + p;
     for (int cb = 0; cb < ncb; ++cb) {
       const f16x8_t a = afr[cb * 64 + lane];
       const f32x16_t acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[0], zero, 0, 0, 0);
@@ -142,11 +147,33 @@ __global__ __launch_bounds__(SM_NT) void stem_mfma_fwd_kernel(const void* __rest
         }
         yv[r >> 1] = pack_bf16x2(o2[0], o2[1]);
       }
-      if (store_ok) {
-        bf16_t* dst = y + pix * C + cb * 32 + 16 * h;
-        reinterpret_cast<uint4*>(dst)[0] = make_uint4(yv[0], yv[1], yv[2], yv[3]);
-        reinterpret_cast<uint4*>(dst)[1] = make_uint4(yv[4], yv[5], yv[6], yv[7]);
-        if (idx != nullptr) *reinterpret_cast<uint4*>(idx + pix * C + cb * 32 + 16 * h) = make_uint4(iv[0], iv[1], iv[2], iv[3]);
+      // stage this channel block (half q of the 64-channel pair)
+      const int q = cb & 1;
+      char* ys = stage + n * SM_YROW + q * 64 + h * 32;
+      reinterpret_cast<uint4*>(ys)[0] = make_uint4(yv[0], yv[1], yv[2], yv[3]);
+      reinterpret_cast<uint4*>(ys)[1] = make_uint4(yv[4], yv[5], yv[6], yv[7]);
+      *reinterpret_cast<uint4*>(stage + 32 * SM_YROW + n * SM_IROW + q * 32 + h * 16) = make_uint4(iv[0], iv[1], iv[2], iv[3]);
+      if (q == 1 || cb == ncb - 1) {        // pair complete (or a last single block): rows of (q + 1) * 64 B / 32 B go out
+        const int cb0 = cb - q, nch = (q + 1) * 4;           // 16-byte chunks of a staged value row
+        const long long row0 = (long long)blockIdx.x * W + SM_PIX * j - 1;     // pixel of staged row 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + (lane >> 3), ch = lane & 7;
+          const int pp = SM_PIX * j - 1 + row;
+          if (row >= 1 && row <= SM_PIX && pp < W && ch < nch)
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y + (row0 + row) * C + cb0 * 32) + ch * 16) =
+                *reinterpret_cast<const uint4*>(stage + row * SM_YROW + ch * 16);
+        }
+        if (idx != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int row = 16 * i + (lane >> 2), ch = lane & 3;
+            const int pp = SM_PIX * j - 1 + row;
+            if (row >= 1 && row <= SM_PIX && pp < W && ch * 2 < nch)
+              *reinterpret_cast<uint4*>(idx + (row0 + row) * C + cb0 * 32 + ch * 16) =
+                  *reinterpret_cast<const uint4*>(stage + 32 * SM_YROW + row * SM_IROW + ch * 16);
+          }
+        }
       }
     }
   }
@@ -162,7 +189,7 @@ int stem_mfma_try_launch(const void* img, const float* stats, const float* w, co
   if (C % 32 != 0 || C > 512 || H % 2 != 0 || H < 4 || W < 1) return 0;
   const int nblk = (W + SM_PIX - 1) / SM_PIX;
   const int RS = (SM_PIX * nblk + 36 + 7) & ~7;
-  const size_t smem = (((size_t)7 * RS * 2 + 15) & ~(size_t)15) + (size_t)(C / 32) * 64 * 16;
+  const size_t smem = (((size_t)7 * RS * 2 + 15) & ~(size_t)15) + (size_t)(C / 32) * 64 * 16 + (size_t)(SM_NT / 64) * SM_STAGE;
   if (smem > 160 * 1024) return 0;
   static bool attr_done = false;
   if (smem > 64 * 1024 && !attr_done) {

@@ -13,8 +13,11 @@ int gemm_halo_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipSt
   if (d->Ho != d->Hi || d->Wo != d->Wi || (d->Wi % 256) != 0) return 0;    // an M tile = 256 pixels of one image row
   if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->c_f32) return 0;
   if ((d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;   // the staged bf16 epilogue
-  if (d->colscale != nullptr || d->act != 0 || d->bias != nullptr || d->preact != nullptr) return 0;  // eval-mode folds stay on the generic kernel
-  if (fwd && d->residual != nullptr) return 0;
+  // forward: raw output (+ BatchNorm column sums) in training, or the eval-mode fold C = relu?(acc * colscale + bias [+ residual])
+  // -- both are paths of the shared staged epilogue; GELU / saved pre-activations do not occur on convolutions
+  if (d->preact != nullptr || (d->act != 0 && d->act != 3)) return 0;
+  if (dgr && (d->colscale != nullptr || d->bias != nullptr || d->act != 0)) return 0;
+  if (fwd && d->residual != nullptr && d->colscale == nullptr) return 0;   // a residual only as part of the eval fold
   if (bn == 192) return fwd ? launch_halo<192, false>(p, st) : launch_halo<192, true>(p, st);
   if (bn == 128) return fwd ? launch_halo<128, false>(p, st) : launch_halo<128, true>(p, st);
   return 0;

@@ -201,6 +201,37 @@ def test_halo_conv_forward_dgrad_exact(cfg):
         assert "gemm_halo_kernel" in outs[12] or "gemm_halo_kernel" in _last_kernel(), (outs, _last_kernel())
 
 
+@pytest.mark.parametrize("cfg", [(2, 2, 256, 192, 192), (1, 3, 512, 128, 384)])
+def test_halo_conv_forward_eval_fold_exact(cfg):
+    """eval-mode BatchNorm (+ residual + ReLU) folded into a halo-staged 3x3 convolution: relu(conv * scale + shift + res),
+    one rounding, against float64 on integer data with power-of-two scales"""
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=60)
+    w = T._ints((Co, Ci, 3, 3), -1, 2, seed=61)
+    y = F.conv2d(x, w, None, stride=1, padding=1).permute(0, 2, 3, 1)
+    g = torch.Generator().manual_seed(62)
+    scale = torch.tensor([0.25, 0.5, 1.0, -0.5])[torch.randint(0, 4, (Co,), generator=g)].double()
+    shift = torch.randint(-8, 9, (Co,), generator=g).double()
+    res = torch.randint(-16, 17, tuple(y.shape), generator=g).double()
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (1, 1), 1)
+    M, cpi = Bn * Hh * Ww, ops.cpad(Ci, BF)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wf = T._pack_fwd(w, cpi).to(BF).cuda()
+    for with_res, relu in ((False, False), (False, True), (True, True)):
+        ref = y * scale + shift + (res if with_res else 0.0)
+        if relu:
+            ref = ref.clamp_min(0.0)
+        for tile in (12, 5):
+            yd = torch.full((Bn, Hh, Ww, Co), 9.0, dtype=BF, device="cuda")
+            ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+                     Cpad=cpi, colscale=scale.float().cuda(), bias=shift.float().cuda(),
+                     residual=res.to(BF).cuda() if with_res else None, act=3 if relu else 0, tile=tile)
+            if tile == 12:
+                assert "gemm_halo_kernel" in _last_kernel(), _last_kernel()
+            assert torch.equal(yd.double().cpu(), ref.to(BF).double()), (with_res, relu, tile, _last_kernel())
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # first block of a stage (resnet18.py:33-37,59-63): the input gradient of the 1x1 stride-s downsample conv formed inside
 # the class-(0,0) launch of the strided 3x3 conv's parity-class dgrad (HtrvtGemmDesc.A2: one more tap)

@@ -46,7 +46,7 @@ class GemmDesc(C.Structure):
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
         ("bias", vp), ("colscale", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
         ("relu_src", vp), ("bnb_x", vp * 2), ("bnb_mean", vp * 2), ("bnb_rstd", vp * 2), ("bnb_partial", vp * 2),
-        ("bnb_tile0", i32),
+        ("bnb_tile0", i32), ("relu_scale", vp), ("relu_shift", vp),
         ("A", vp), ("B", vp), ("C", vp),
     ]
 

@@ -479,6 +479,12 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
     p.bnb_partial[t] = d->bnb_partial[t];
   }
   p.bnb_tile0 = d->bnb_tile0;
+  p.relu_sc = d->relu_scale;
+  p.relu_sf = d->relu_shift;
+  HTRVT_REQUIRE((d->relu_scale == nullptr) == (d->relu_shift == nullptr), "htrvt_gemm: relu_scale and relu_shift go together");
+  HTRVT_REQUIRE(d->relu_scale == nullptr || (d->bnb_partial[0] != nullptr && d->bnb_partial[1] == nullptr && d->residual == nullptr &&
+                                             d->relu_src == nullptr && d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h < 0),
+                "htrvt_gemm: relu_scale / relu_shift need exactly one bnb set, no residual, no relu_src, an unstrided conv dgrad");
   const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   p.cls_h = p.cls_w = -1;
   p.extra_off = 0;

@@ -60,6 +60,9 @@ struct KParams {
   const float* bnb_rstd[2];
   float* bnb_partial[2];
   int bnb_tile0;
+  // ReLU mask recomputed from bnb_x[0] (HtrvtGemmDesc.relu_scale / relu_shift), or NULL
+  const float* relu_sc;
+  const float* relu_sf;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

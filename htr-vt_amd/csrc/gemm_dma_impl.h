@@ -322,6 +322,11 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   const bool bnb = DGRAD && FIXED_COLS && PASSES == 1 && p.bnb_partial[0] != nullptr;
   const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
   float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
+  // ReLU mask recomputed from bnb_x[0]: the forward's BatchNorm scale / shift of this lane's 8 columns
+  const bool relux = bnb && !bnb2 && p.relu_sc != nullptr;
+  float rsc[8], rsf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rsc[e] = rsf[e] = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -333,6 +338,10 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
       for (int e = 0; e < 8; ++e) {
         bmu[0][e] = p.bnb_mean[0][nc + e];
         brs[0][e] = p.bnb_rstd[0][nc + e];
+        if (relux) {
+          rsc[e] = p.relu_sc[nc + e];
+          rsf[e] = p.relu_sf[nc + e];
+        }
         if (bnb2) {
           bmu[1][e] = p.bnb_mean[1][nc + e];
           brs[1][e] = p.bnb_rstd[1][nc + e];
@@ -430,12 +439,13 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
     constexpr int U = ((DGRAD && FNB >= 2) || (NW_TOTAL > 8 && (RUNTIME_FLAGS || FPIN == 1))) ? 2 : 4;
     const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
     const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
+    constexpr bool RELU_X = FRELU == 3;       // mask from bnb_x[0] through (rsc, rsf); needs FNB >= 1
     const bool has_pre_in = FPIN == 1 || (FPIN == 2 && rt_pre_in);
     const bool has_pre_out = FPOUT == 1 || (FPOUT == 2 && rt_pre_out);
     const bool has_gelu = FGELU == 1 || (FGELU == 2 && rt_gelu);
     const int nb = FNB == 3 ? rt_nb : FNB;
     const bool relu_last = FRLAST == 1 || (FRLAST == 2 && rt_rlast);
-    const bool ew = has_res || has_relu || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
+    const bool ew = has_res || has_relu || RELU_X || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
     for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
       unsigned o[U];
       bool ok[U];
@@ -528,6 +538,13 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
         }
+        if constexpr (RELU_X) {  // the same ReLU, its input rebuilt from the BatchNorm input that is loaded for the sums anyway
+          const uint4 xr = rbx[0][u];
+          const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
+                              bf16lo(xr.z), bf16hi(xr.z), bf16lo(xr.w), bf16hi(xr.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(x[e], rsc[e], rsf[e]) > 0.f ? v[e] : 0.f;
+        }
         if (nb > 0) {  // train-mode BatchNorm backward sums of the layer this gradient feeds: sum g, sum g * xhat
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -557,7 +574,8 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   if constexpr (DGRAD) {   // conv dgrad: [residual] [ReLU mask + 1 or 2 BatchNorm-backward sum sets]
-    if (!rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
+    if (relux) walk(I0{}, I3{}, I0{}, I0{}, I0{}, I1{}, I0{});      // host guarantees: one bnb set, no residual, no relu_src
+    else if (!rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
     else if (rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
     else if (!rt_res && rt_relu && rt_nb == 1 && !rt_rlast) walk(I0{}, I1{}, I0{}, I0{}, I0{}, I1{}, I0{});
     else if (rt_res && rt_relu && rt_nb == 1 && !rt_rlast) walk(I1{}, I1{}, I0{}, I0{}, I0{}, I1{}, I0{});

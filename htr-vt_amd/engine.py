@@ -99,8 +99,15 @@ class Engine:
         # bf16: every conv / Linear weight is re-packed by ONE table-driven launch per step and the conv weight gradients are
         # unpacked by one launch per DP bucket (csrc/relayout.hip) instead of one launch per tensor (47 per step)
         self.table_relayout = True
+        self.relu_mask_from_bn = True   # conv2's fused dgrad epilogue: ReLU mask from the BatchNorm input it reads anyway (no read of a1)
         self.merge_bn_backward = True   # first block of a stage: bn2 + downsample-BN backward in one pass over the shared gradient
         self._rl_cache, self._pending_unpack = {}, []
+        # A/B runs on one box: HTRVT_ENGINE_OVERRIDE="relu_mask_from_bn=0,table_relayout=0" flips boolean switches above
+        for kv in filter(None, os.environ.get("HTRVT_ENGINE_OVERRIDE", "").split(",")):
+            k, _, v = kv.partition("=")
+            if not isinstance(getattr(self, k.strip(), None), bool):
+                raise ValueError(f"HTRVT_ENGINE_OVERRIDE: no boolean engine switch {k!r}")
+            setattr(self, k.strip(), v.strip() not in ("0", "false", "False", ""))
         # first block of a stage, bf16: the input gradient of the 1x1 downsample conv is formed INSIDE the class-(0,0) launch
         # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
         # plus a residual round trip of the whole input gradient
@@ -350,13 +357,14 @@ class Engine:
     def _dgrad_by_class(self, g):
         return self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
 
-    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None):
+    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None, relu_bn=None):
         """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only).
         extra = dy2 (parity-class path only): the gradient of the block's 1x1 downsample conv output, allocated right
         behind dy; wd is then the joint pack of _conv_w_joint_dgrad and dx also receives the 1x1 conv's input gradient."""
         cpo = cpad(g.Co, self.dtype)
         dx = self._empty(g.B, g.Hi, g.Wi, g.Ci)
         assert extra is None or self._dgrad_by_class(g)
+        assert relu_bn is None or (not self._dgrad_by_class(g) and relu_src is None and residual is None and bnb is not None and len(bnb) == 1)
         wtaps = g.taps + (1 if extra is not None else 0)       # taps per row of the packed weight
         if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
@@ -386,7 +394,7 @@ class Engine:
                 main.wait_stream(st_)
             return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
-             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb)
+             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb, relu_bn=relu_bn)
         return dx
 
     def _conv_wgrad(self, dy, x, g: ConvGeom, dw):
@@ -932,8 +940,9 @@ class Engine:
             if can_fuse(blk["g2"]):
                 rows1 = self.dgrad_tiles(blk["g2"])
                 part1 = self._empty(rows1, 2, C, dtype=torch.float32)
-                g1 = self.conv_dgrad(dcb, wd2, blk["g2"], relu_src=blk["a1"],
-                                     bnb=[(blk["ca"], blk["bn_a"][2], blk["bn_a"][3], part1)])
+                # a1 = relu(bn1(ca)): the mask is recomputed from ca (read for the sums anyway) instead of reading a1
+                rk = dict(relu_bn=(blk["bn_a"][0], blk["bn_a"][1])) if self.relu_mask_from_bn else dict(relu_src=blk["a1"])
+                g1 = self.conv_dgrad(dcb, wd2, blk["g2"], bnb=[(blk["ca"], blk["bn_a"][2], blk["bn_a"][3], part1)], **rk)
                 dca, _ = self.bn_backward_finish(part1, rows1, g1, None, blk["ca"], p + ".bn1", P, G, blk["bn_a"][2],
                                                  blk["bn_a"][3], out=dca_out)
                 del g1

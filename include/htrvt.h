@@ -90,13 +90,20 @@ typedef struct HtrvtGemmDesc {
    * relu_src: same shape/type as C; C = (relu_src > 0) ? value : 0, applied after `residual` (backward of ReLU).
    * bnb_*[t], t = 0,1: BatchNorm-backward sums of the (masked) gradient written to C against up to two raw conv
    * outputs bnb_x[t] (same shape as C): bnb_partial[t][bnb_tile0 + m_tile][2][N] = { sum g, sum g*(x-mean)*rstd }.
-   * bnb_partial[0] == NULL disables it. */
+   * bnb_partial[0] == NULL disables it.
+   * relu_scale / relu_shift (float32 [N], both or neither; with bnb_partial[0] set, bnb_partial[1], residual and relu_src
+   * NULL): the ReLU whose backward this is was applied to BatchNorm(bnb_x[0]) -- conv -> bn1 -> relu -> conv2 inside a
+   * BasicBlock, resnet18.py:27-31 -- so its mask is recomputed from the BatchNorm input the epilogue reads anyway:
+   * C = (bnb_x[0] * relu_scale[n] + relu_shift[n] > 0) ? value : 0, the same fused multiply-add htrvt_bn_apply formed in
+   * the forward.  Saves the read of the activation tensor (403 MB per layer-1 launch). */
   const void* relu_src;
   const void* bnb_x[2];
   const float* bnb_mean[2];
   const float* bnb_rstd[2];
   float* bnb_partial[2];
   int32_t bnb_tile0;
+  const float* relu_scale;
+  const float* relu_shift;
   const void* A;
   const void* B;
   void* C;

@@ -59,11 +59,12 @@ def test_f32_training_iterations_bitwise_reproducible(shape):
         assert torch.equal(s1[k], s2[k]), k
 
 
-@pytest.mark.parametrize("flag", ["table_relayout", "merge_bn_backward"])
+@pytest.mark.parametrize("flag", ["table_relayout", "merge_bn_backward", "relu_mask_from_bn"])
 def test_launch_merges_are_bit_neutral_bf16(flag):
     """bf16 engine, two AdamW steps with slab split-K, every gradient and parameter bit-identical with and without
     * table_relayout: the one-launch weight re-pack / gradient unpack (csrc/relayout.hip) against per-tensor launches,
-    * merge_bn_backward: bn2 + downsample-BN backward of a stage's first block in one pass over the shared gradient."""
+    * merge_bn_backward: bn2 + downsample-BN backward of a stage's first block in one pass over the shared gradient,
+    * relu_mask_from_bn: conv2's dgrad epilogue rebuilds the ReLU mask from bn1's input instead of reading the activation."""
     from htrvt_amd.trainer import Trainer
     cfg = O.Config(80, (64, 512), embed_dim=256, depth=4, num_heads=4)
     x, targets, lengths = O.synthetic_batch(8, cfg.H, cfg.W, cfg.nb_cls, cfg.num_patches, seed=3)

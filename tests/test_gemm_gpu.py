@@ -303,6 +303,19 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
                          relu_src=relu_src.to(dtype).cuda(), bnb=bnb)
     assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
 
+    if nbn == 1 and not with_res and not eng._dgrad_by_class(geom):
+        # the same mask recomputed from the BatchNorm input (HtrvtGemmDesc.relu_scale / relu_shift): a1 = relu(x * sc + sf)
+        sc = torch.tensor([0.5, 1.0, -1.0, 2.0])[torch.randint(0, 4, (Ci,), generator=gen)].double()
+        sf = torch.randint(-3, 4, (Ci,), generator=gen).double()
+        g2_ref = dx * ((bnx[0] * sc + sf) > 0)
+        parts2 = torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda")
+        out2 = eng.conv_dgrad(dyd, wd, geom, bnb=[(bnb[0][0], bnb[0][1], bnb[0][2], parts2)], relu_bn=(sc.float().cuda(), sf.float().cuda()))
+        assert torch.equal(out2.double().cpu(), g2_ref), float((out2.double().cpu() - g2_ref).abs().max())
+        xhat = (bnx[0] - mean[0]) * rstd[0]
+        gg, xx = g2_ref.reshape(-1, Ci), xhat.reshape(-1, Ci)
+        want = torch.stack([torch.stack([gg[r0:r0 + 256].sum(0), (gg[r0:r0 + 256] * xx[r0:r0 + 256]).sum(0)]) for r0 in range(0, gg.shape[0], 256)])
+        assert torch.equal(parts2.double().cpu(), want)
+
     # expected partial rows: 256-row M tiles of every launch, in launch order
     sh, sw = stride
     by_class = eng._dgrad_by_class(geom)

@@ -155,6 +155,10 @@ def main():
         plain("fc1 dgrad            32768x768x3072", M, D, F)
         plain("qkv dgrad            32768x768x2304", M, D, F3)
         plain("proj dgrad           32768x768x768", M, D, D)
+    if "lwgrad" in args.only:   # the encoder's Linear weight gradients dW[out][in] = dy^T x, K = 32768 tokens, over split factors
+        for tag, Mo, No in (("fc1", 3072, 768), ("fc2", 768, 3072), ("qkv", 2304, 768), ("proj", 768, 768)):
+            for split in ((3, 4, 5, 6, 7, 8, 10, 16) if tag != "proj" else (8, 16, 24, 28, 32)):
+                tn(f"TN wgrad-{tag} {Mo}x{No}xK32768 split {split}", Mo, No, 32768, split)
     if not args.only or "mlp" in args.only:
         M, D, F = 32768, 768, 3072
         bias = torch.rand(F, device=dev)

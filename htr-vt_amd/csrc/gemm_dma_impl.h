@@ -321,7 +321,9 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   constexpr int RB_STEP = FIXED_COLS ? NWAVES / GROUPS : 1;
   const bool bnb = DGRAD && FIXED_COLS && PASSES == 1 && p.bnb_partial[0] != nullptr;
   const bool bnb2 = bnb && p.bnb_partial[1] != nullptr;
-  float bs1[2][8], bs2[2][8], bmu[2][8], brs[2][8];
+  // per-lane column sums of this workgroup's rows: sum g and the RAW sum g * x; the centring (x - mean) * rstd is applied
+  // once per column when the tile's partial row is written (two VALU operations and 16 registers per set less in the walk)
+  float bs1[2][8], bs2[2][8];
   // ReLU mask recomputed from bnb_x[0]: the forward's BatchNorm scale / shift of this lane's 8 columns
   const bool relux = bnb && !bnb2 && p.relu_sc != nullptr;
   float rsc[8], rsf[8];
@@ -330,22 +332,14 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = bmu[t][e] = brs[t][e] = 0.f;
-  if (bnb) {
+    for (int e = 0; e < 8; ++e) bs1[t][e] = bs2[t][e] = 0.f;
+  if (relux) {
     const int nc = n0 + (wave % GROUPS) * 32 + lg * 8;
     if (nc < p.N) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        bmu[0][e] = p.bnb_mean[0][nc + e];
-        brs[0][e] = p.bnb_rstd[0][nc + e];
-        if (relux) {
-          rsc[e] = p.relu_sc[nc + e];
-          rsf[e] = p.relu_sf[nc + e];
-        }
-        if (bnb2) {
-          bmu[1][e] = p.bnb_mean[1][nc + e];
-          brs[1][e] = p.bnb_rstd[1][nc + e];
-        }
+        rsc[e] = p.relu_sc[nc + e];
+        rsf[e] = p.relu_sf[nc + e];
       }
     }
   }
@@ -436,7 +430,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
     // items in flight per wave: 4, or 2 where two BatchNorm sum sets (64 accumulators), the GELU' path or the
     // run-time-flag fallback leave no registers for more under the 12-wave (168 VGPR) budget
     constexpr bool RUNTIME_FLAGS = FRES == 2 || FRELU == 2 || FPIN == 2 || FPOUT == 2 || FGELU == 2 || FRLAST == 2 || FNB == 3;
-    constexpr int U = ((DGRAD && FNB >= 2) || (NW_TOTAL > 8 && (RUNTIME_FLAGS || FPIN == 1))) ? 2 : 4;
+    constexpr int U = ((DGRAD && FNB >= 3) || (NW_TOTAL > 8 && (RUNTIME_FLAGS || FPIN == 1))) ? 2 : 4;
     const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
     const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
     constexpr bool RELU_X = FRELU == 3;       // mask from bnb_x[0] through (rsc, rsf); needs FNB >= 1
@@ -556,7 +550,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
             for (int e = 0; e < 8; ++e) {
               const float gv = ok[u] ? v[e] : 0.f;
               bs1[t][e] += gv;
-              bs2[t][e] += gv * ((x[e] - bmu[t][e]) * brs[t][e]);
+              bs2[t][e] = fmaf(gv, x[e], bs2[t][e]);
             }
           }
         }
@@ -657,7 +651,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
             }
             float* dst = p.bnb_partial[t] + (long long)(p.bnb_tile0 + tile_m) * 2 * p.N;
             dst[n] = a;
-            dst[p.N + n] = q2;
+            dst[p.N + n] = (q2 - p.bnb_mean[t][n] * a) * p.bnb_rstd[t][n];     // sum g * (x - mean) * rstd
           }
         }
       }

@@ -299,10 +299,6 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
     rows = eng.dgrad_tiles(geom)
     parts = [torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nbn)]
     bnb = [(bnx[t].to(dtype).cuda(), mean[t].float().cuda(), rstd[t].float().cuda(), parts[t]) for t in range(nbn)]
-    out = eng.conv_dgrad(dyd, wd, geom, residual=res.to(dtype).cuda() if with_res else None,
-                         relu_src=relu_src.to(dtype).cuda(), bnb=bnb)
-    assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
-
     if nbn == 1 and not with_res and not eng._dgrad_by_class(geom):
         # the same mask recomputed from the BatchNorm input (HtrvtGemmDesc.relu_scale / relu_shift): a1 = relu(x * sc + sf)
         sc = torch.tensor([0.5, 1.0, -1.0, 2.0])[torch.randint(0, 4, (Ci,), generator=gen)].double()
@@ -315,6 +311,10 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
         gg, xx = g2_ref.reshape(-1, Ci), xhat.reshape(-1, Ci)
         want = torch.stack([torch.stack([gg[r0:r0 + 256].sum(0), (gg[r0:r0 + 256] * xx[r0:r0 + 256]).sum(0)]) for r0 in range(0, gg.shape[0], 256)])
         assert torch.equal(parts2.double().cpu(), want)
+
+    out = eng.conv_dgrad(dyd, wd, geom, residual=res.to(dtype).cuda() if with_res else None,
+                         relu_src=relu_src.to(dtype).cuda(), bnb=bnb)
+    assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
 
     # expected partial rows: 256-row M tiles of every launch, in launch order
     sh, sw = stride

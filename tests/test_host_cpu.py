@@ -32,6 +32,59 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.lib.htrvt_version() >= 100
 
 
+def test_ctypes_structures_match_the_header(tmp_path):
+    """the ctypes mirrors of HtrvtGemmDesc / HtrvtRelayoutJob (htr-vt_amd/_lib.py) against the C compiler's layout of
+    include/htrvt.h: size and the offset of every field"""
+    import ctypes
+    import subprocess
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd import _lib
+    structs = {"HtrvtGemmDesc": _lib.GemmDesc, "HtrvtRelayoutJob": _lib.RelayoutJob}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "htrvt.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_relayout_plan_is_host_side_and_refuses_malformed_jobs():
+    """htrvt_relayout_plan (csrc/relayout.hip) only fills the workgroup ranges of a job table: callable without a GPU"""
+    import ctypes
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd._lib import RelayoutJob, lib, RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD
+
+    def job(kind, d0, d1, taps=0, cpi=0, cpo=0, row_taps=0, tap0=0, dst0=8, dst1=8):
+        j = RelayoutJob()
+        j.src, j.dst0, j.dst1, j.kind, j.d0, j.d1 = 8, dst0, dst1, kind, d0, d1
+        j.taps, j.cpad_in, j.cpad_out, j.row_taps, j.tap0 = taps, cpi, cpo, row_taps, tap0
+        return j
+
+    jobs = (RelayoutJob * 4)(job(RELAYOUT_PACK_CONV, 192, 64, 9, 64, 192, 9, 0),          # 6 x 2 tiles of 32 x 32
+                             job(RELAYOUT_CAST_TRANSPOSE, 80, 768, cpi=80),                 # 12 x 2 tiles of 64 x 64
+                             job(RELAYOUT_UNPACK_WGRAD, 40, 24, 9, 64, dst1=None),          # 2 x 1
+                             job(RELAYOUT_PACK_CONV, 48, 24, 1, 64, 64, 10, 9, dst0=None))  # joint-pack slot 9 of 10: 2 x 1
+    assert lib.htrvt_relayout_plan(jobs, 4) == 12 + 24 + 2 + 2
+    assert [j.tile0 for j in jobs] == [0, 12, 36, 38] and [j.tiles_x for j in jobs] == [2, 12, 1, 1]
+    for bad in (job(RELAYOUT_PACK_CONV, 48, 24, 9, 64, 64, 9, 1),           # tap slots 1 .. 9 of 9
+                job(RELAYOUT_PACK_CONV, 48, 24, 10, 64, 64, 10, 0),         # more taps than a tile holds
+                job(RELAYOUT_PACK_CONV, 48, 24, 9, 16, 64, 9, 0),           # padded row shorter than the channels
+                job(RELAYOUT_CAST_TRANSPOSE, 80, 768, cpi=72),              # transposed rows shorter than the matrix
+                job(RELAYOUT_UNPACK_WGRAD, 40, 24, 9, 64, dst0=None),       # nowhere to add the gradient
+                job(7, 4, 4)):
+        assert lib.htrvt_relayout_plan((RelayoutJob * 1)(bad), 1) < 0
+    assert lib.htrvt_relayout_plan((RelayoutJob * 1)(jobs[0]), 0) < 0 and lib.htrvt_relayout_plan(None, 1) < 0
+
+
 def test_create_model_matches_reference_init(golden_dir):
     from htrvt_amd.model import HTR_VT
     g = np.load(os.path.join(golden_dir, "create_model_init.npz"), allow_pickle=False)

@@ -9,8 +9,9 @@ int gemm_halo_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipSt
   const bool fwd = d->gather == HTRVT_GATHER_CONV_FWD, dgr = d->gather == HTRVT_GATHER_CONV_DGRAD;
   if (!(fwd || dgr) || d->dtype != HTRVT_BF16) return 0;
   if (d->tile != 0 && d->tile != 4 && d->tile != 12) return 0;      // 12: this kernel where eligible; 5: the generic gather (A/B)
-  if (d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->cls_h >= 0) return 0;
-  if (d->Ho != d->Hi || d->Wo != d->Wi || (d->Wi % 256) != 0) return 0;    // an M tile = 256 pixels of one image row
+  if (d->kh != 3 || d->kw != 3 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->cls_h >= 0) return 0;
+  if (d->sh != 1 && !(fwd && d->sh == 2)) return 0;                           // forward also with a row stride of 2 (layer1.0.conv1)
+  if (d->Ho != (d->Hi - 1) / d->sh + 1 || d->Wo != d->Wi || (d->Wi % 256) != 0) return 0;    // an M tile = 256 pixels of one image row
   if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->c_f32) return 0;
   if ((d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;   // the staged bf16 epilogue
   // forward: raw output (+ BatchNorm column sums) in training, or the eval-mode fold C = relu?(acc * colscale + bias [+ residual])

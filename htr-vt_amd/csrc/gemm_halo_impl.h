@@ -46,8 +46,11 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
   const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Hh = DGRAD ? p.Ho : p.Hi, Ww = DGRAD ? p.Wo : p.Wi, Cs = DGRAD ? p.Co : p.Ci;   // gathered tensor [B,Hh,Ww,Cs]
-  const int rowi = m0 / Ww, w0 = m0 - rowi * Ww;      // image row (b * Hh + h) and first column of this tile
-  const int hrow = rowi % Hh;
+  const int rowi = m0 / Ww, w0 = m0 - rowi * Ww;      // row (b * Hm + h) of the M index space and first column of this tile
+  // forward with a row stride (sh = 2, W stride 1: the first conv of layer 1): M rows are OUTPUT rows, Hm = Ho of them per
+  // image, and kernel row gdy of output row h reads input row h * sh + gdy - 1; dgrad is served at stride 1 only
+  const int Hm = DGRAD ? Hh : p.Ho;
+  const int bimg = rowi / Hm, hrow = rowi - bimg * Hm;
   const int NC = p.Cpad / BK;                           // 64-channel chunks per tap
   const int NG = 3 * NC;                                // groups = (kernel row, chunk); k-tiles = 3 * NG
 
@@ -71,9 +74,9 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
 
   // A halo half `half` (pieces 20 half .. 20 half + 19) of group (gdy, gcc) into A stage `ast`; gvalid false: zero fill
   auto issueA = [&](int half, int ast, int gdy, int gcc, bool gvalid) {
-    const int hh = hrow + (DGRAD ? 1 - gdy : gdy - 1);
+    const int hh = DGRAD ? hrow + 1 - gdy : hrow * p.sh + gdy - 1;
     const bool rowok = gvalid && (unsigned)hh < (unsigned)Hh;
-    const unsigned gbase = (unsigned)(((rowi - hrow + hh) * Ww) * Cs + gcc * BK) * 2u;
+    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww) * Cs + gcc * BK) * 2u;
     const bool chok = gcc * BK + cgA * 8 < Cs;
 #pragma unroll
     for (int i = 0; i < H::NP_AH; ++i) {

@@ -1,4 +1,4 @@
-// gemm_hwgrad.hip -- instantiations + host-side eligibility of the halo-staged 3x3 stride-1 conv weight-gradient kernels
+// gemm_hwgrad.hip -- instantiations + host-side eligibility of the halo-staged 3x3 (W stride 1) conv weight-gradient kernels
 // (gemm_hwgrad_impl.h); called from gemm_dma_try_launch before the generic MN-major gather kernel.
 #include "gemm_hwgrad_impl.h"
 
@@ -14,8 +14,8 @@ int gemm_hwgrad_bn(const HtrvtGemmDesc* d) {
 bool gemm_hwgrad_serves(const HtrvtGemmDesc* d) {
   if (d->gather != HTRVT_GATHER_CONV_WGRAD || d->dtype != HTRVT_BF16) return false;
   if (d->tile != 0 && d->tile != 13) return false;      // 13: this kernel where eligible; 3 / 4 / 6: the generic kernels (A/B)
-  if (d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
-  if (d->Ho != d->Hi || d->Wo != d->Wi || (d->Wi % 64) != 0) return false;     // a k-tile = 64 pixels of one image row
+  if (d->kh != 3 || d->kw != 3 || (d->sh != 1 && d->sh != 2) || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;   // row stride 2: layer1.0.conv1
+  if (d->Ho != (d->Hi - 1) / d->sh + 1 || d->Wo != d->Wi || (d->Wi % 64) != 0) return false;     // a k-tile = 64 pixels of one image row
   if (!d->c_f32 || d->batch > 1 || d->Cpad % 64 != 0 || d->M != 9 * d->Cpad || d->N != d->Co) return false;
   if (d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr) return false;
   const long long lim = (1ll << 31) - 64;

@@ -106,10 +106,11 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
   int iq_row = kbeg / Ww, iq_w0 = kbeg - iq_row * Ww, iq_k = kbeg;
   auto issue = [&](int stage) {
     const unsigned sbase = lds0 + stage * H::STAGE;
-    const int hrow = iq_row % Hh;
-    const int hh = hrow + dyi - 1;
+    // pixel row iq_row = (image, output row ho) of dY; the x row of kernel row dyi is ho * sh + dyi - 1 (sh = 1 or 2, W stride 1)
+    const int bimg = iq_row / p.Ho, hrow = iq_row - bimg * p.Ho;
+    const int hh = hrow * p.sh + dyi - 1;
     const bool rowok = iq_k < kend && (unsigned)hh < (unsigned)Hh;
-    const unsigned gbase = (unsigned)(((iq_row - hrow + hh) * Ww + iq_w0 - 1) * p.Ci + ci0) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + iq_w0 - 1) * p.Ci + ci0) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
 #pragma unroll
     for (int i = 0; i < H::NPX_MAX; ++i) {
       if (i < npx) {      // wave-uniform

@@ -256,7 +256,7 @@ class Engine:
         row length a multiple of 64), or None where the generic kernel serves the convolution"""
         if self.dtype != torch.bfloat16 or not self.halo_wgrad:
             return None
-        if (g.kh, g.kw, g.sh, g.sw, g.ph, g.pw) != (3, 3, 1, 1, 1, 1) or g.Wi % 64:
+        if (g.kh, g.kw, g.sw, g.ph, g.pw) != (3, 3, 1, 1, 1) or g.sh not in (1, 2) or g.Wi % 64:
             return None
         cp = cpad(g.Ci, self.dtype)
         cc = 128 if cp % 128 == 0 else 64

@@ -163,6 +163,48 @@ HALO = [  # B, H, W, Ci, Co
     (2, 3, 256, 96, 256),      # Ci = 96 -> Cpad 128: the last chunk is half padding; Co = 256 -> 128-column tiles
     (1, 2, 768, 128, 64),      # three tiles per row, Co = 64: 64-column route (generic kernel) must still be right
 ]
+HALO_STRIDED = [  # B, H, W, Ci, Co: stride (2, 1), the first conv of layer 1 (forward and weight gradient on the halo kernels)
+    (2, 8, 256, 192, 192),
+    (3, 5, 256, 64, 128),      # odd H: the last output row's third kernel row is padding
+]
+
+
+@pytest.mark.parametrize("cfg", HALO_STRIDED)
+def test_halo_conv_row_stride_forward_wgrad_exact(cfg):
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=80)
+    w = T._ints((Co, Ci, 3, 3), -2, 3, seed=81).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=(2, 1), padding=1)
+    dy = T._ints(tuple(y.shape), -2, 3, seed=82)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (2, 1), 1)
+    M = Bn * geom.Ho * geom.Wo
+    cpi = ops.cpad(Ci, BF)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wf = T._pack_fwd(w.detach(), cpi).to(BF).cuda()
+    y_nhwc = y.detach().permute(0, 2, 3, 1)
+    for tile in (12, 5):
+        yd = torch.full((Bn, geom.Ho, geom.Wo, Co), 9.0, dtype=BF, device="cuda")
+        nmt = ops.gemm_num_mtiles(M, Co, BF, gather=ops.GATHER_CONV_FWD)
+        cs = torch.zeros(nmt, 2, Co, dtype=torch.float32, device="cuda")
+        ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+                 Cpad=cpi, colstats=cs, tile=tile)
+        if tile == 12:
+            assert "gemm_halo_kernel" in _last_kernel(), _last_kernel()
+        assert torch.equal(yd.double().cpu(), y_nhwc.to(BF).double()), (tile, _last_kernel())
+        assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    want = T._pack_fwd(w.grad, cpi).permute(1, 2, 0)            # [taps][Cpad][Co]
+    for tile, split_k in ((13, 8), (13, 3), (3, 8)):
+        base = T._ints((9, cpi, Co), -5, 6, seed=83)
+        dwp = base.float().cuda()
+        ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                 gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, tile=tile)
+        if tile == 13:
+            assert "gemm_hwgrad_kernel" in _last_kernel(), _last_kernel()
+        assert torch.equal(dwp.double().cpu(), base + want), (tile, split_k, float((dwp.double().cpu() - base - want).abs().max()))
+
 
 
 @pytest.mark.parametrize("cfg", HALO)

@@ -65,6 +65,18 @@ struct KParams {
   const float* relu_sf;
 };
 
+// Few-row Linear launches (the per-rank batches of a strong-scaling run: M = 4096 at 16 images per GPU): with N <= 1024 a
+// 256 x 192 tiling leaves three quarters of the CUs idle (16 x 4 = 64 workgroups); 256 x 128 tiles with three LDS stages
+// give 1.5x the workgroups and measured +20...30 % (tools/bench_gemm.py --only encsmall --tiles 0 8: fc2 forward 57 -> 42 us,
+// fc1 dgrad 53 -> 40, qkv dgrad 42 -> 33 at M = 4096; +15...25 % at M = 8192; wide N and M = 32768 lose, so they stay)
+inline bool gemm_small_m_prefers_bn128(const HtrvtGemmDesc* d) {
+  if (d->tile != 0 || d->gather != HTRVT_GATHER_NONE || d->dtype != HTRVT_BF16) return false;
+  if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR || d->batch > 1 || d->split_k > 1) return false;
+  if (d->N > 1024 || d->N % 128 != 0) return false;
+  const long long tiles192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
+  return tiles192 <= 128;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);

@@ -36,7 +36,7 @@ int pick_bn(const HtrvtGemmDesc* d) {
   // tile count stops filling whole rounds of 256 CUs (N=768 / 2304 Linear layers) -> conv wgrad and explicit only
   if (N % 256 == 0 && !fused && d->colscale == nullptr && d->act != 3 && (d->tile == 6 || (d->tile == 0 && d->gather == HTRVT_GATHER_CONV_WGRAD))) return 256;
   if (N <= 64) return 64;
-  if (N <= 128 || d->tile == 7 || d->tile == 8) return 128;   // 7 / 8: experiment selectors, 128-column tiles with 2 / 3 stages
+  if (N <= 128 || d->tile == 7 || d->tile == 8 || gemm_small_m_prefers_bn128(d)) return 128;   // 7 / 8: experiment selectors, 128-column tiles with 2 / 3 stages
   const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;
   return p192 <= p128 ? 192 : 128;
 }
@@ -114,7 +114,7 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
   const bool spec = use_loader_waves(d);
   if (bn == 256) return gemm_dma_dispatch_bn256(d, p, zdim, st, false);
   if (bn == 64) return gemm_dma_dispatch_bn64(d, p, zdim, st, spec);
-  if (bn == 128) return d->tile == 8 ? gemm_dma_dispatch_bn128_s3(d, p, zdim, st, spec) : gemm_dma_dispatch_bn128(d, p, zdim, st, spec);
+  if (bn == 128) return (d->tile == 8 || gemm_small_m_prefers_bn128(d)) ? gemm_dma_dispatch_bn128_s3(d, p, zdim, st, spec) : gemm_dma_dispatch_bn128(d, p, zdim, st, spec);
   return gemm_dma_dispatch_bn192(d, p, zdim, st, spec);
 }
 

@@ -155,6 +155,20 @@ def main():
         plain("fc1 dgrad            32768x768x3072", M, D, F)
         plain("qkv dgrad            32768x768x2304", M, D, F3)
         plain("proj dgrad           32768x768x768", M, D, D)
+    if "encsmall" in args.only:   # the encoder's Linear layers at the per-rank batches of a strong-scaling run: M = 4096 (B = 16), 8192 (B = 32)
+        D, F3, F = 768, 2304, 3072
+        for M in (4096, 8192):
+            bq, bf, bd = torch.rand(F3, device=dev), torch.rand(F, device=dev), torch.rand(D, device=dev)
+            res = rnd(M, D)
+            pre = torch.empty(M, F, dtype=dt, device=dev)
+            pre_in = rnd(M, F)
+            plain(f"qkv fwd +bias        {M}x2304x768", M, F3, D, bias=bq)
+            plain(f"proj fwd +bias+res   {M}x768x768", M, D, D, bias=bd, residual=res)
+            plain(f"fc1 fwd +bias+gelu+pre {M}x3072x768", M, F, D, bias=bf, act=1, preact=pre)
+            plain(f"fc2 fwd +bias+res    {M}x768x3072", M, D, F, bias=bd, residual=res)
+            plain(f"fc2 dgrad *gelu'     {M}x3072x768", M, F, D, act=2, preact=pre_in)
+            plain(f"fc1 dgrad            {M}x768x3072", M, D, F)
+            plain(f"qkv dgrad            {M}x768x2304", M, D, F3)
     if "lwgrad" in args.only:   # the encoder's Linear weight gradients dW[out][in] = dy^T x, K = 32768 tokens, over split factors
         for tag, Mo, No in (("fc1", 3072, 768), ("fc2", 768, 3072), ("qkv", 2304, 768), ("proj", 768, 768)):
             for split in ((3, 4, 5, 6, 7, 8, 10, 16) if tag != "proj" else (8, 16, 24, 28, 32)):

@@ -38,6 +38,10 @@ int pick_bn(const HtrvtGemmDesc* d) {
   if (N <= 64) return 64;
   if (N <= 128 || d->tile == 7 || d->tile == 8 || gemm_small_m_prefers_bn128(d)) return 128;   // 7 / 8: experiment selectors, 128-column tiles with 2 / 3 stages
   const int p192 = (N + 191) / 192 * 192, p128 = (N + 127) / 128 * 128;
+  // few output pixels (layer 3 at 16 images per GPU: 32 M tiles): 128-column tiles fill 192 instead of 128 CUs
+  if ((d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_DGRAD) && d->tile == 0 && d->cls_h < 0 && N >= 256 &&
+      N % 128 == 0 && (long long)((d->M + BM_ - 1) / BM_) * (p192 / 192) <= 128)
+    return 128;
   return p192 <= p128 ? 192 : 128;
 }
 

@@ -27,11 +27,11 @@ def _build(cfg, seed, dtype=torch.float32):
     return sd, m.cuda().train()
 
 
-def _one_run(cfg, B, steps=2):
+def _one_run(cfg, B, steps=2, dtype=torch.float32):
     """`steps` full SAM(AdamW) iterations from a fixed start; returns every gradient of the last pass and every
     parameter / buffer afterwards"""
     from htrvt_amd.trainer import Trainer
-    _, m = _build(cfg, 7)
+    _, m = _build(cfg, 7, dtype=dtype)
     tr = Trainer(m, max_lr=1e-3, betas=(0.9, 0.99), weight_decay=0.5)
     x, targets, lengths = O.synthetic_batch(B, cfg.H, cfg.W, cfg.nb_cls, cfg.num_patches, seed=3)
     xd = x.cuda()
@@ -53,6 +53,18 @@ def test_f32_training_iterations_bitwise_reproducible(shape):
     cfg = O.Config(80, (64, W), embed_dim=D, depth=depth, num_heads=heads)
     l1, g1, s1 = _one_run(cfg, B)
     l2, g2, s2 = _one_run(cfg, B)
+    assert l1 == l2
+    assert torch.equal(g1, g2), int((g1 != g2).sum())
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+
+
+def test_bf16_training_iterations_bitwise_reproducible():
+    """round 3: the bf16 throughput path splits K through ordered slabs by default (Engine.deterministic), every other
+    reduction was already order-fixed: two SAM(AdamW) iterations at d256 / B = 8 repeat bit for bit"""
+    cfg = O.Config(80, (64, 512), embed_dim=256, depth=4, num_heads=4)
+    l1, g1, s1 = _one_run(cfg, 8, dtype=torch.bfloat16)
+    l2, g2, s2 = _one_run(cfg, 8, dtype=torch.bfloat16)
     assert l1 == l2
     assert torch.equal(g1, g2), int((g1 != g2).sum())
     for k in s1:

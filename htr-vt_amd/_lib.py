@@ -28,7 +28,7 @@ class RelayoutJob(C.Structure):
     ]
 
 
-RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS = 0, 1, 2, 64
+RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS, RELAYOUT_ARG_JOBS = 0, 1, 2, 64, 48
 
 
 class GemmDesc(C.Structure):
@@ -99,6 +99,7 @@ PROTOTYPES = {
     "htrvt_cast_f32": (i32, [vp, vp, i64, i32, vp]),
     "htrvt_relayout_plan": (i32, [vp, i32]),
     "htrvt_relayout": (i32, [vp, i32, i32, i32, vp]),
+    "htrvt_relayout_host": (i32, [vp, i32, i32, i32, vp]),
     "htrvt_relpos_bias_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_relpos_bias_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_cast_transpose_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),

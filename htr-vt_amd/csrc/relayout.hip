@@ -182,6 +182,38 @@ __global__ __launch_bounds__(NT) void relayout_jobs_kernel(const HtrvtRelayoutJo
   relayout_tile<T>(J, (int)blockIdx.x - J.tile0, smem);
 }
 
+// The same launch with the table passed BY VALUE in the kernel-argument segment (<= HTRVT_RELAYOUT_ARG_JOBS jobs): nothing
+// to upload, nothing to keep alive, no cache to invalidate when a gradient buffer moves -- what the engine uses.
+struct RelayoutArgs {
+  int njobs;
+  int pad_[3];
+  HtrvtRelayoutJob j[HTRVT_RELAYOUT_ARG_JOBS];
+};
+static_assert(sizeof(RelayoutArgs) <= 4096, "kernel-argument segment");
+
+template <typename T>
+__global__ __launch_bounds__(NT) void relayout_args_kernel(const RelayoutArgs a) {
+  typedef const __attribute__((address_space(4))) RelayoutArgs KA;
+  (void)a;
+  KA* ka = (KA*)__builtin_amdgcn_kernarg_segment_ptr();      // indexed in place: a by-value copy would live in scratch
+  __shared__ float smem[SMEM_FLOATS];
+  __shared__ int which;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool le = lane < ka->njobs && ka->j[lane < HTRVT_RELAYOUT_ARG_JOBS ? lane : 0].tile0 <= (int)blockIdx.x;
+    const unsigned long long m = __ballot(le);
+    if (lane == 0) which = __popcll(m) - 1;
+  }
+  __syncthreads();
+  const int w = which;
+  HtrvtRelayoutJob J;
+  J.src = ka->j[w].src, J.dst0 = ka->j[w].dst0, J.dst1 = ka->j[w].dst1, J.kind = ka->j[w].kind, J.d0 = ka->j[w].d0, J.d1 = ka->j[w].d1;
+  J.taps = ka->j[w].taps, J.cpad_in = ka->j[w].cpad_in, J.cpad_out = ka->j[w].cpad_out, J.row_taps = ka->j[w].row_taps;
+  J.tap0 = ka->j[w].tap0, J.tile0 = ka->j[w].tile0, J.tiles_x = ka->j[w].tiles_x;
+  __syncthreads();
+  relayout_tile<T>(J, (int)blockIdx.x - J.tile0, smem);
+}
+
 int job_tiles(HtrvtRelayoutJob* j) {
   if (j->src == nullptr || j->d0 <= 0 || j->d1 <= 0) return -1;
   if (j->kind == HTRVT_RELAYOUT_CAST_TRANSPOSE) {
@@ -235,6 +267,22 @@ extern "C" int htrvt_relayout(const HtrvtRelayoutJob* jobs_dev, int njobs, int t
     hipLaunchKernelGGL(relayout_jobs_kernel<bf16_t>, dim3(total_tiles), dim3(NT), 0, (hipStream_t)stream, jobs_dev, njobs);
   else
     hipLaunchKernelGGL(relayout_jobs_kernel<float>, dim3(total_tiles), dim3(NT), 0, (hipStream_t)stream, jobs_dev, njobs);
+  return check_launch("relayout");
+}
+
+// jobs: a PLANNED table in HOST memory (htrvt_relayout_plan), njobs <= HTRVT_RELAYOUT_ARG_JOBS; it is copied into the launch
+extern "C" int htrvt_relayout_host(const HtrvtRelayoutJob* jobs, int njobs, int total_tiles, int dtype, void* stream) {
+  HTRVT_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= HTRVT_RELAYOUT_ARG_JOBS && total_tiles >= 1, "htrvt_relayout_host: 1..%d planned jobs",
+                HTRVT_RELAYOUT_ARG_JOBS);
+  HTRVT_REQUIRE(dtype == HTRVT_BF16 || dtype == HTRVT_F32, "htrvt_relayout_host: dtype");
+  RelayoutArgs a = {};
+  a.njobs = njobs;
+  for (int i = 0; i < njobs; ++i) a.j[i] = jobs[i];
+  HTRVT_REQUIRE(a.j[0].tile0 == 0 && a.j[njobs - 1].tile0 < total_tiles, "htrvt_relayout_host: the table is not planned");
+  if (dtype == HTRVT_BF16)
+    hipLaunchKernelGGL(relayout_args_kernel<bf16_t>, dim3(total_tiles), dim3(NT), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(relayout_args_kernel<float>, dim3(total_tiles), dim3(NT), 0, (hipStream_t)stream, a);
   return check_launch("relayout");
 }
 

@@ -19,7 +19,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import lib, check, RelayoutJob, RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS
+from ._lib import lib, check, RelayoutJob, RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_ARG_JOBS
 from .ops import KMAJOR, MNMAJOR, GATHER_CONV_DGRAD, GATHER_CONV_FWD, GATHER_CONV_WGRAD, ConvGeom, cpad, dt, gemm, ptr, stream
 
 LN_EPS = 1e-6       # HTR_VT.py:252
@@ -101,7 +101,7 @@ class Engine:
         self.table_relayout = True
         self.relu_mask_from_bn = True   # conv2's fused dgrad epilogue: ReLU mask from the BatchNorm input it reads anyway (no read of a1)
         self.merge_bn_backward = True   # first block of a stage: bn2 + downsample-BN backward in one pass over the shared gradient
-        self._rl_cache, self._pending_unpack = {}, []
+        self._pending_unpack = []
         # A/B runs on one box: HTRVT_ENGINE_OVERRIDE="relu_mask_from_bn=0,table_relayout=0" flips boolean switches above
         for kv in filter(None, os.environ.get("HTRVT_ENGINE_OVERRIDE", "").split(",")):
             k, _, v = kv.partition("=")
@@ -425,24 +425,15 @@ class Engine:
 
     # ------------------------------------------------------------------ table-driven re-layouts (csrc/relayout.hip)
     def _relayout(self, jobs):
-        """run RelayoutJobs, <= 64 per launch.  The planned table lives in device memory and is reused while the pointers
-        and sizes in it stay the same (flat parameter / gradient buffers and the pack buffers are persistent)."""
-        for i in range(0, len(jobs), RELAYOUT_MAX_JOBS):
-            chunk = jobs[i:i + RELAYOUT_MAX_JOBS]
+        """run RelayoutJobs, <= 48 per launch: the table is planned on the host and travels in the kernel-argument segment
+        (no device copy to keep alive, nothing to refresh when autograd hands out new gradient buffers)"""
+        for i in range(0, len(jobs), RELAYOUT_ARG_JOBS):
+            chunk = jobs[i:i + RELAYOUT_ARG_JOBS]
             arr = (RelayoutJob * len(chunk))(*chunk)
-            sig = bytes(arr)
-            ent = self._rl_cache.get(sig)
-            if ent is None:
-                total = lib.htrvt_relayout_plan(arr, len(chunk))
-                if total < 0:
-                    raise RuntimeError(lib.htrvt_last_error().decode())
-                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
-                dev = host.to(self.dev, non_blocking=True)
-                torch.cuda.current_stream().synchronize()     # once per table: later launches may come from another stream
-                if len(self._rl_cache) >= 32:
-                    self._rl_cache.clear()
-                ent = self._rl_cache[sig] = (dev, total)
-            check(lib.htrvt_relayout(ptr(ent[0]), len(chunk), ent[1], self.dti, stream()), "relayout")
+            total = lib.htrvt_relayout_plan(arr, len(chunk))
+            if total < 0:
+                raise RuntimeError(lib.htrvt_last_error().decode())
+            check(lib.htrvt_relayout_host(arr, len(chunk), total, self.dti, stream()), "relayout")
 
     def _repack_all(self, P, save):
         """bf16: refresh every stale conv pack / Linear copy in one launch (what _conv_w / _conv_w_joint_dgrad / _lin_w /

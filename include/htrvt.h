@@ -294,6 +294,10 @@ typedef struct HtrvtRelayoutJob {
 } HtrvtRelayoutJob;
 int htrvt_relayout_plan(HtrvtRelayoutJob* jobs_host, int njobs);   /* returns the launch's workgroup count, < 0 on a bad job */
 int htrvt_relayout(const HtrvtRelayoutJob* jobs_dev, int njobs, int total_tiles, int dtype, void* stream);
+/* the same launch from a planned table in HOST memory, copied into the kernel-argument segment (no device copy of the
+ * table to keep alive or to refresh when a gradient buffer moves); njobs <= HTRVT_RELAYOUT_ARG_JOBS */
+#define HTRVT_RELAYOUT_ARG_JOBS 48
+int htrvt_relayout_host(const HtrvtRelayoutJob* jobs_host, int njobs, int total_tiles, int dtype, void* stream);
 /* Linear weight w [rows = out][cols = in] float32 -> dst [rows][cols] (may be NULL) and dst_t [cols][ld_t] = w^T in
  * `dtype` (bfloat16), columns rows .. ld_t-1 of dst_t zero: the K-major B operand of the Linear dgrad GEMM
  * dx[M][in] = dy[M][out] * w (HTR_VT.py:22-37 backward), so that forward and dgrad run the same kernel. */

@@ -44,12 +44,18 @@ def test_relayout_table_runs_every_job_of_a_launch():
     g = torch.Generator().manual_seed(5)
     ints = lambda *shape: torch.randint(-64, 64, shape, generator=g).float().cuda()
 
+    calls = [0]
+
     def run(jobs, dti):
         arr = (RelayoutJob * len(jobs))(*jobs)
         total = lib.htrvt_relayout_plan(arr, len(jobs))
         assert total > 0, lib.htrvt_last_error()
-        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
-        check(lib.htrvt_relayout(ptr(dev), len(jobs), total, dti, stream()), "relayout")
+        if calls[0] % 2 == 0:       # table in device memory ...
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+            check(lib.htrvt_relayout(ptr(dev), len(jobs), total, dti, stream()), "relayout")
+        else:                       # ... or copied into the kernel-argument segment (what the engine does)
+            check(lib.htrvt_relayout_host(arr, len(jobs), total, dti, stream()), "relayout_host")
+        calls[0] += 1
         torch.cuda.synchronize()
 
     convs = [(192, 64, 9), (40, 24, 9), (384, 192, 1), (37, 21, 9), (16, 8, 4)]
@@ -73,6 +79,10 @@ def test_relayout_table_runs_every_job_of_a_launch():
         d1 = torch.full((cols, ld), 7.0, dtype=bf, device="cuda")
         jobs.append(_job(RELAYOUT_CAST_TRANSPOSE, w, d0, d1, rows, cols, 0, ld))
         lins.append((w, d0, d1, rows))
+    run(jobs, 1)
+    for _, fwd_, dgr_, _, _ in want:      # second pass through the other launch form, from cleared destinations
+        fwd_.zero_(), dgr_.zero_()
+    joint.zero_()
     run(jobs, 1)
     for w, fwd, dgr, Co, Ci in want:
         assert torch.equal(fwd[:, :, :Ci].float(), w.permute(0, 2, 1)) and torch.equal(dgr[:, :, :Co].float(), w.permute(1, 2, 0))

@@ -543,16 +543,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
       f32x16_t st, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
+      // One wave per SIMD: nothing but this wave's own instruction stream covers an LDS read, so the fragments of a whole
+      // product are requested first and the MFMAs follow (read -> wait -> MFMA one at a time cost ~150 cycles per MFMA)
+      // the tile's per-query constants (lse2, delta) of this 32-query block: requested ahead of the MFMAs that hide them
+      // (the bias variant has no registers to spare for either: it keeps the one-at-a-time order)
+      float4 lsq[4], deq[4];
+      if constexpr (!BIAS) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qt, la, 32 * c, s), kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dot, la, 32 * c, s), vf[s], dp, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          lsq[g] = *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf);
+          deq[g] = *reinterpret_cast<const float4*>(cst + QT + 32 * c + 8 * g + 4 * hf);
+        }
+      }
+      constexpr int NSG = BIAS ? 1 : (NS >= 4 ? 4 : NS);      // k-steps whose fragments are requested together
+#pragma unroll
+      for (int s0 = 0; s0 < NS; s0 += NSG) {
+        bf16x8_t fq[NSG], fd[NSG];
+#pragma unroll
+        for (int s = 0; s < NSG; ++s) {
+          fq[s] = row_frag<HD>(qt, la, 32 * c, s0 + s);
+          fd[s] = row_frag<HD>(dot, la, 32 * c, s0 + s);
+        }
+#pragma unroll
+        for (int s = 0; s < NSG; ++s) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s], kf[s0 + s], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s], vf[s0 + s], dp, 0, 0, 0);
+        }
       }
       // accumulator register i is query 32 c + (i & 3) + 8 (i >> 2) + 4 hf of the tile
       static_for<0, 4>([&](auto G) {
         constexpr int g = decltype(G)::value;
-        const float4 ls = *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf);
-        const float4 de = *reinterpret_cast<const float4*>(cst + QT + 32 * c + 8 * g + 4 * hf);
+        const float4 ls = BIAS ? *reinterpret_cast<const float4*>(cst + 32 * c + 8 * g + 4 * hf) : lsq[g];
+        const float4 de = BIAS ? *reinterpret_cast<const float4*>(cst + QT + 32 * c + 8 * g + 4 * hf) : deq[g];
         const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
         static_for<0, 4>([&](auto J) {
           constexpr int j = decltype(J)::value, i = 4 * g + j;
@@ -575,10 +597,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8_t pb = acc_frag(st, s), dsb = acc_frag(dp, s);
+        if constexpr (!BIAS) {
+          bf16x8_t tv[ND], tk[ND];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dot, la, 32 * c, s, d), pb, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qt, la, 32 * c, s, d), dsb, dk[d], 0, 0, 0);
+          for (int d = 0; d < ND; ++d) {
+            tv[d] = tr_frag<HD>(dot, la, 32 * c, s, d);
+            tk[d] = tr_frag<HD>(qt, la, 32 * c, s, d);
+          }
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tv[d], pb, dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[d], dsb, dk[d], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dot, la, 32 * c, s, d), pb, dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qt, la, 32 * c, s, d), dsb, dk[d], 0, 0, 0);
+          }
         }
       }
     }

@@ -102,12 +102,6 @@ class Engine:
         self.relu_mask_from_bn = True   # conv2's fused dgrad epilogue: ReLU mask from the BatchNorm input it reads anyway (no read of a1)
         self.merge_bn_backward = True   # first block of a stage: bn2 + downsample-BN backward in one pass over the shared gradient
         self._pending_unpack = []
-        # A/B runs on one box: HTRVT_ENGINE_OVERRIDE="relu_mask_from_bn=0,table_relayout=0" flips boolean switches above
-        for kv in filter(None, os.environ.get("HTRVT_ENGINE_OVERRIDE", "").split(",")):
-            k, _, v = kv.partition("=")
-            if not isinstance(getattr(self, k.strip(), None), bool):
-                raise ValueError(f"HTRVT_ENGINE_OVERRIDE: no boolean engine switch {k!r}")
-            setattr(self, k.strip(), v.strip() not in ("0", "false", "False", ""))
         # first block of a stage, bf16: the input gradient of the 1x1 downsample conv is formed INSIDE the class-(0,0) launch
         # of the strided 3x3 conv's dgrad (one more tap, HtrvtGemmDesc.A2) instead of by its own parity-class launches
         # plus a residual round trip of the whole input gradient
@@ -123,6 +117,12 @@ class Engine:
         self.saved = None
         self._bn_train = True
         self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
+        # A/B runs on one box: HTRVT_ENGINE_OVERRIDE="relu_mask_from_bn=0,table_relayout=0" flips boolean switches above
+        for kv in filter(None, os.environ.get("HTRVT_ENGINE_OVERRIDE", "").split(",")):
+            k, _, v = kv.partition("=")
+            if not isinstance(getattr(self, k.strip(), None), bool):
+                raise ValueError(f"HTRVT_ENGINE_OVERRIDE: no boolean engine switch {k!r}")
+            setattr(self, k.strip(), v.strip() not in ("0", "false", "False", ""))
 
     # ------------------------------------------------------------------ small helpers
     def _empty(self, *shape, dtype=None):

@@ -440,10 +440,30 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
     const int nb = FNB == 3 ? rt_nb : FNB;
     const bool relu_last = FRLAST == 1 || (FRLAST == 2 && rt_rlast);
     const bool ew = has_res || has_relu || RELU_X || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
+    // ReLU-from-BatchNorm-input variant (one side input per item): the x vectors of BOTH rounds are requested before the
+    // first round is processed -- one exposed memory round trip per tile instead of two (the accumulators are dead here, the
+    // 32 registers are free).  Items of round 0 / 1 sit in two named sets, selected per round (no dynamic register index).
+    constexpr bool PRE = FRELU == 3 && FNB == 1 && ITEMS == NWAVES * 2 * U;
+    uint4 pbx0[PRE ? U : 1], pbx1[PRE ? U : 1];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int k = 0; k < 2 * U; ++k) {
+        const int id = wave + k * NWAVES;
+        const int rbk = id / GROUPS, cg = id - rbk * GROUPS;
+        const int half = (cg * 32) / (TNP * 32);
+        const int nbc = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
+        const int m = m0 + rbk * 16 + lr;
+        const unsigned off = (m < p.M && nbc < p.N) ? (unsigned)m * ldc + (unsigned)nbc : 0u;
+        const uint4 v = *reinterpret_cast<const uint4*>(bx0 + off);
+        if (k < U) pbx0[k % U] = v;
+        else pbx1[k % U] = v;
+      }
+    }
     for (int id0 = wave; id0 < ITEMS; id0 += NWAVES * U) {
       unsigned o[U];
       bool ok[U];
       uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
+      const bool first_round = id0 == wave;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int id = id0 + u * NWAVES;
@@ -474,7 +494,12 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
         if (has_res) rres[u] = *reinterpret_cast<const uint4*>(resb + o[u]);
         if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(relub + o[u]);
         if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(preb + o[u]);
-        if (nb > 0) rbx[0][u] = *reinterpret_cast<const uint4*>(bx0 + o[u]);
+        if constexpr (PRE) {
+          const uint4 a_ = pbx0[u], b_ = pbx1[u];
+          rbx[0][u] = first_round ? a_ : b_;
+        } else if (nb > 0) {
+          rbx[0][u] = *reinterpret_cast<const uint4*>(bx0 + o[u]);
+        }
         if (nb > 1) rbx[1][u] = *reinterpret_cast<const uint4*>(bx1 + o[u]);
         const char* a0 = smem + (cg * 32) * CST + rbk * 32 + lane_lds;
         const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));

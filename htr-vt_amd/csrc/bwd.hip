@@ -731,7 +731,7 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
   // Scalars are formed in double on the host (Python floats are doubles) and rounded once.  One rounding per operation:
   // no FMA contraction in this function; `/` and sqrtf are the correctly rounded forms (hipcc default).
 #pragma clang fp contract(off)
-  // g, m, v are streamed once per step (700 MB with p for the 25 M parameters of the d768 model): non-temporal accesses,
+  // g, m, v are streamed once per step (1.5 GB with p for the 53.5 M parameters of the d768 model): non-temporal accesses,
   // so that the lines do not displace the weights the next forward re-reads through L2; p is stored normally
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {

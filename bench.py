@@ -66,6 +66,12 @@ def parse():
     ap.add_argument("--parallel-classes", action="store_true", help="A/B: parity-class dgrad launches of a strided conv on separate streams")
     ap.add_argument("--no-fused-attention", action="store_true", help="A/B: batched GEMMs + row softmax instead of csrc/attention.hip")
     ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
+    ap.add_argument("--traffic-json", default=None, help="PMC traffic summary (tools/collect_pmc.sh -> tools/pmc_summary.py) "
+                    "the roofline's `traffic` is read from; default: the newest profiles/r*_pmc_traffic.json")
+    ap.add_argument("--graph", default="off", choices=["off", "on"], help="replay the training step as ONE captured HIP "
+                    "graph (Trainer.capture_step) inside the timed region instead of ~360 eager launches")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the strong-scaling sub-record (global batch "
+                    "128 split over the ranks, graph-replayed) that follows the timed weak-scaling steps")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU iterations (about 10 s of host work in total)")
     return ap.parse_args()
@@ -171,6 +177,77 @@ def build_model(args, dtype):
                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), compute_dtype=dtype)
 
 
+def newest_traffic_json():
+    """profiles/rNN_pmc_traffic.json of the highest round (written by tools/collect_pmc.sh + tools/pmc_summary.py)"""
+    import glob
+    import re
+    best = None
+    for pth in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        mt = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(pth))
+        if mt and (best is None or int(mt.group(1)) > best[0]):
+            best = (int(mt.group(1)), pth)
+    return best[1] if best else None
+
+
+def strong_leg(args, dev, world, rank, dtype, use_dist, steps=10, warmup=3):
+    """global batch `--batch` split evenly over the ranks, the step replayed as one HIP graph (eager if the capture is
+    refused), barrier + synchronize on both sides, max over ranks -- the same protocol as the main timed region"""
+    from htrvt_amd.trainer import Trainer
+    Bs = args.batch // world
+    torch.manual_seed(123)
+    model = build_model(args, dtype).to(dev).train()
+    N = model.num_patches
+    x, tg, tl = synthetic_batch(Bs, 64, args.width, args.nb_cls, N, seed=rank)
+    x = x.to(dev)
+    torch.manual_seed(7)
+    keep = model.generate_span_mask(N, 0.4, 8)
+    tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world, use_collectives=use_dist and world > 1)
+    tr.step(x, tg, tl, keep_mask=keep)
+    graphed, note = True, None
+    try:
+        gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True)
+
+        def one():
+            return gs.step(gs.img, tg, tl, keep_mask=keep)
+    except Exception as e:      # noqa: BLE001 -- a refused capture (e.g. a collective that cannot be recorded) is reported, not fatal
+        graphed, note = False, f"graph capture refused ({type(e).__name__}: {str(e)[:120]}); eager launches"
+
+        def one():
+            return tr.step(x, tg, tl, keep_mask=keep)
+    # every rank takes the same branch: a refused capture on one rank would desynchronise the collectives
+    if use_dist:
+        flag = torch.tensor([1 if graphed else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if graphed and int(flag.item()) == 0:
+            graphed, note = False, "graph capture refused on another rank; eager launches"
+
+            def one():       # noqa: F811
+                return tr.step(x, tg, tl, keep_mask=keep)
+    for _ in range(warmup):
+        one()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_ = float(t.item())
+    out = {"global_batch": Bs * world, "batch_per_gpu": Bs, "steps": steps, "warmup": warmup, "ms_per_step": round(dt_ / steps * 1e3, 3),
+           "value": round(Bs * world * steps / dt_, 1), "unit": "line-images/s", "graph_replay": graphed}
+    if note:
+        out["note"] = note
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.  This process has made no
     HIP call yet and never will (it only waits), each rank is a fresh interpreter with the torch.distributed.run
@@ -262,6 +339,12 @@ def main():
                 ema.update(model, num_updates=it[0] / 2)
                 it[0] += 1
                 return l_
+        elif args.graph == "on":
+            tr.step(x, tg, tl, keep_mask=keep)          # lazily sized workspaces, one-time kernel attributes
+            gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True)
+
+            def one_step():
+                return gs.step(gs.img, tg, tl, keep_mask=keep)
         else:
             def one_step():
                 return tr.step(x, tg, tl, keep_mask=keep)
@@ -286,6 +369,15 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
+    # ---- strong-scaling leg (N > 1, after the timed weak-scaling steps; not part of `value`): the global batch of 128
+    # split over the ranks -- SURVEY.md 8(d) asks for both curves, the driver's one command records both ----
+    strong = None
+    if world > 1 and args.scaling == "weak" and not (args.forward_only or args.sam or args.no_strong_leg) and args.batch % world == 0:
+        strong = strong_leg(args, dev, world, rank, dtype, use_dist)
+    elif world == 1 and args.scaling == "weak" and not (args.forward_only or args.sam):
+        strong = {"global_batch": B, "batch_per_gpu": B, "ms_per_step": round(ms, 3), "value": round(value, 1),
+                  "unit": "line-images/s", "note": "one GPU: the strong- and the weak-scaling step are the same step"}
+
     # ---- roofline leg: HIP events around every MFMA launch of two extra steps (not part of `value`) ----
     roof = None
     # every rank runs the two extra steps (they contain collectives); only rank 0 records events
@@ -293,8 +385,10 @@ def main():
         ops.PROFILE = {}
     if not args.forward_only:
         saved_overlap, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False   # one stream: events time ONE kernel
+    # (a replayed graph has no per-launch events: the two profiled steps always run as eager launches)
+    prof_step = one_step if (args.forward_only or args.sam or args.graph != "on") else (lambda: tr.step(x, tg, tl, keep_mask=keep))
     for _ in range(2):
-        one_step()
+        prof_step()
     torch.cuda.synchronize()
     if not args.forward_only:
         tr.engine.overlap_wgrad = saved_overlap
@@ -328,13 +422,14 @@ def main():
         shapes = [{"shape": f"{names[k_[3]]} M={k_[4]} N={k_[5]} K={k_[6]} batch={k_[7]}", "launches_per_step": n_,
                    "avg_ms": round(av_, 4), "tflops": round(fl_ / (av_ * 1e-3) / 1e12, 1)} for _, k_, fl_, av_, n_ in sym["shapes"][:4]]
         traffic, traffic_src = None, None
-        try:   # HBM bytes per launch (mean over the symbol's launches) from the committed PMC passes of this round's build
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        try:   # HBM bytes per launch (mean over the symbol's launches) from the newest committed PMC passes
+            tj = args.traffic_json or newest_traffic_json()
+            with open(tj) as f:
                 pm = json.load(f)
             ent = pm["symbols"].get(symname)
             if ent is not None and B == 128 and args.width == 1024 and args.dtype == "bf16" and not args.forward_only:
-                traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], "profiles/r03_pmc_traffic.json"
-        except (OSError, KeyError, ValueError):
+                traffic, traffic_src = ent["traffic_bytes_per_launch_mean"], os.path.relpath(tj, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
             pass
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -348,7 +443,7 @@ def main():
         model_tag = f"d{args.embed_dim}/{args.depth}L/{args.heads}h, nb_cls {args.nb_cls}"
         what = ("fwd+CTC (eval)" if args.forward_only else "SAM(AdamW) 2x(fwd+bwd+CTC)+EMA" if args.sam else "fwd+bwd+CTC")
         eng_ = eng if args.forward_only else tr.engine
-        out = {"metric": f"line-images/sec (64x{args.width}, B={B * world if args.scaling == 'strong' else B}) {what}",
+        out = {"metric": f"line-images/sec (64x{args.width}, global B={B * world}, {B} per GPU) {what}",
                "value": round(value, 1), "unit": "line-images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -361,8 +456,11 @@ def main():
                           "tokens_per_image": N, "mask": "span 0.4/8 (run/iam.sh)", "parallelism": f"dp{world}",
                           "engine_flags": {k: getattr(eng_, k) for k in ("fuse_stem_forward", "fuse_bn_backward", "overlap_wgrad",
                                                                           "fused_attention", "deterministic", "parallel_classes")},
+                          "graph_replay": args.graph == "on" and not (args.forward_only or args.sam),
                           "loss": float(loss.mean().item()) if loss is not None else None},
                "roofline": roof}
+        if strong is not None:
+            out["strong"] = strong
         if (not args.no_parity_path and world == 1 and args.dtype == "bf16" and not args.forward_only and not args.sam
                 and args.scaling == "weak"):
             out["parity_path"] = parity_path(args, dev, x, tg, tl, keep)

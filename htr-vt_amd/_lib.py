@@ -29,6 +29,7 @@ class RelayoutJob(C.Structure):
 
 
 RELAYOUT_PACK_CONV, RELAYOUT_CAST_TRANSPOSE, RELAYOUT_UNPACK_WGRAD, RELAYOUT_MAX_JOBS, RELAYOUT_ARG_JOBS = 0, 1, 2, 64, 48
+HTRVT_ADAMW_SCALARS = 8
 
 
 class GemmDesc(C.Structure):
@@ -110,6 +111,8 @@ PROTOTYPES = {
     "htrvt_ema_update": (i32, [vp, i32, i64, f64, vp]),
     "htrvt_ctc_greedy_decode": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp]),
     "htrvt_adamw": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
+    "htrvt_adamw_scalars": (i32, [f64, f64, f64, f64, f64, i32, vp]),
+    "htrvt_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "htrvt_line_max_scale": (i32, []),
     "htrvt_line_prepare": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_ctc_workspace_floats": (C.c_size_t, [i32, i32, i32]),

@@ -723,14 +723,21 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 }
 
 // decoupled weight decay Adam over one flat float32 buffer (torch.optim.AdamW semantics)
+// DEV: the seven derived scalars come from device memory (`hyper`, written by the host before a captured graph is
+// replayed: a graph bakes its kernel arguments, and lr / the step number change every step) instead of the argument list
+template <bool DEV>
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float decay, float w1, float b2,
-                                                   float w2, float eps, float bc2s, float neg_step) {
+                                                   float w2, float eps, float bc2s, float neg_step,
+                                                   const float* __restrict__ hyper) {
+#pragma clang fp contract(off)
+  if constexpr (DEV) {
+    decay = hyper[0]; w1 = hyper[1]; b2 = hyper[2]; w2 = hyper[3]; eps = hyper[4]; bc2s = hyper[5]; neg_step = hyper[6];
+  }
   // the statement order of torch.optim.AdamW's single-tensor step (torch/optim/adamw.py): p *= 1 - lr*wd;
   // m.lerp_(g, 1 - beta1); v = v*beta2 + (1 - beta2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p += (-lr/bc1) * m/denom.
   // Scalars are formed in double on the host (Python floats are doubles) and rounded once.  One rounding per operation:
   // no FMA contraction in this function; `/` and sqrtf are the correctly rounded forms (hipcc default).
-#pragma clang fp contract(off)
   // g, m, v are streamed once per step (1.5 GB with p for the 53.5 M parameters of the d768 model): non-temporal accesses,
   // so that the lines do not displace the weights the next forward re-reads through L2; p is stored normally
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -960,10 +967,33 @@ extern "C" int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t
                            double eps, double weight_decay, int step, void* stream) {
   HTRVT_REQUIRE(n % 4 == 0 && step >= 1, "htrvt_adamw: n must be a multiple of 4 and step >= 1");
   HTRVT_REQUIRE(p && g && m && v, "htrvt_adamw: null buffer");
+  float h[HTRVT_ADAMW_SCALARS];
+  htrvt_adamw_scalars(lr, beta1, beta2, eps, weight_decay, step, h);
+  hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
+                     (long long)(n / 4), h[0], h[1], h[2], h[3], h[4], h[5], h[6], (const float*)nullptr);
+  return check_launch("adamw");
+}
+
+extern "C" int htrvt_adamw_scalars(double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                                   float* out) {
+  HTRVT_REQUIRE(out && step >= 1, "htrvt_adamw_scalars: null output or step < 1");
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long long)(n / 4),
-                     (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)bc2s, (float)(-(lr / bc1)));
-  return check_launch("adamw");
+  out[0] = (float)(1.0 - lr * weight_decay);
+  out[1] = (float)(1.0 - beta1);
+  out[2] = (float)beta2;
+  out[3] = (float)(1.0 - beta2);
+  out[4] = (float)eps;
+  out[5] = (float)bc2s;
+  out[6] = (float)(-(lr / bc1));
+  out[7] = 0.f;
+  return 0;
+}
+
+extern "C" int htrvt_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream) {
+  HTRVT_REQUIRE(n % 4 == 0, "htrvt_adamw_dev: n must be a multiple of 4");
+  HTRVT_REQUIRE(p && g && m && v && hyper_dev, "htrvt_adamw_dev: null buffer");
+  hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid_for(n / 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
+                     (long long)(n / 4), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, hyper_dev);
+  return check_launch("adamw_dev");
 }

@@ -114,6 +114,7 @@ class Engine:
         self.deterministic = True
         self._side, self._side_active = None, False
         self._call_started = None      # event at the start of the previous forward() (host run-ahead throttle)
+        self.capturing = False         # True while Trainer.capture_step records the step into a HIP graph
         self.saved = None
         self._bn_train = True
         self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
@@ -591,10 +592,13 @@ class Engine:
         # in the middle of the run (measured: 120 ms per step for the first ten steps after warm-up).  So: before
         # enqueueing call k the host waits until the device has STARTED call k-1 -- one call of run-ahead, which is all
         # the device needs to never run dry.
-        if self._call_started is not None:
-            self._call_started.synchronize()
-        self._call_started = torch.cuda.Event()
-        self._call_started.record()
+        # (while a HIP graph is being captured -- Trainer.capture_step -- nothing may wait on the host and there is no
+        # run-ahead to bound: the replaying caller throttles itself)
+        if not self.capturing:
+            if self._call_started is not None:
+                self._call_started.synchronize()
+            self._call_started = torch.cuda.Event()
+            self._call_started.record()
         st = stream()
         sv = {} if save else None
         C1 = s.D // 4

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from . import mark_weights_dirty
+from . import mark_weights_dirty, trace
 
 
 class FlatParams:
@@ -130,15 +130,24 @@ class Trainer:
     def forward_backward(self, img, targets, lengths, keep_mask=None):
         """forward + CTC + backward on this rank's shard; the (already averaged) gradients land in the flat
         gradient buffer.  Returns the local mean loss (device scalar)."""
-        from .ctc import ctc_forward_backward, stage_targets
-        eng, fl = self.engine, self.flat
-        fl.check_views()     # a caller that re-bound p.data (reference SAM.second_step, model.to()) must rebuild the Trainer
+        from .ctc import stage_targets
+        self.flat.check_views()     # a caller that re-bound p.data (reference SAM.second_step, model.to()) must rebuild the Trainer
         staged = stage_targets(targets, lengths, img.device)   # before the forward is enqueued (see stage_targets)
+        return self._forward_backward_staged(img, staged, keep_mask)
+
+    def _forward_backward_staged(self, img, staged, keep_mask):
+        """the device work of forward_backward: label arrays already on the device (`staged`), keep_mask None or a host /
+        device [N] tensor.  This is the body a captured step records (GraphedStep)."""
+        from .ctc import ctc_forward_backward
+        eng, fl = self.engine, self.flat
         fl.flat_g.zero_()
-        y = eng.forward(self.P, img, keep_mask=keep_mask, train=True, save=True)
-        nll, dy = ctc_forward_backward(y, targets, lengths, want_grad=True, grad_scale=1.0 / self.world, staged=staged)
-        eng.backward(self.P, fl.G, dy, after_encoder=fl.reduce_encoder_bucket, after_layer3=fl.reduce_layer3_bucket)
-        fl.reduce_stem_bucket()
+        with trace.range_("htrvt.forward"):
+            y = eng.forward(self.P, img, keep_mask=keep_mask, train=True, save=True)
+        with trace.range_("htrvt.ctc"):
+            nll, dy = ctc_forward_backward(y, None, None, want_grad=True, grad_scale=1.0 / self.world, staged=staged)
+        with trace.range_("htrvt.backward"):
+            eng.backward(self.P, fl.G, dy, after_encoder=fl.reduce_encoder_bucket, after_layer3=fl.reduce_layer3_bucket)
+            fl.reduce_stem_bucket()
         return nll.mean()
 
     def optimizer_step(self, lr=None):
@@ -146,9 +155,10 @@ class Trainer:
         from .ops import ptr, stream
         self.step_count += 1
         fl = self.flat
-        check(lib.htrvt_adamw(ptr(fl.flat_p), ptr(fl.flat_g), ptr(self.flat_m), ptr(self.flat_v), fl.flat_p.numel(),
-                              float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
-                              self.step_count, stream()), "adamw")
+        with trace.range_("htrvt.adamw"):
+            check(lib.htrvt_adamw(ptr(fl.flat_p), ptr(fl.flat_g), ptr(self.flat_m), ptr(self.flat_v), fl.flat_p.numel(),
+                                  float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
+                                  self.step_count, stream()), "adamw")
         # the kernel wrote through raw pointers (no autograd version bump): invalidate the packed-weight cache
         mark_weights_dirty(self.model)
 
@@ -156,6 +166,14 @@ class Trainer:
         loss = self.forward_backward(img, targets, lengths, keep_mask)
         self.optimizer_step(lr)
         return loss
+
+    def capture_step(self, img, max_target_len, masked=True):
+        """Record step() -- gradient clear, forward, CTC, backward (incl. the bucketed all-reduces when a process group
+        is in use), AdamW -- into ONE HIP graph (~360 launches per step are launch-bound at small per-rank
+        batches).  Call after at least one eager step() of the same batch shape (lazily sized workspaces, one-time
+        kernel attributes and the engine's streams exist then).  Returns a GraphedStep; its step() has step()'s
+        signature and results (bit-identical: same kernels, same order, same scalars)."""
+        return GraphedStep(self, img, max_target_len, masked)
 
     def sam_first_step(self, rho=0.05):
         """SAM.first_step (utils/sam.py:15-27, adaptive=False) on the flat buffers: |g| by a two-stage reproducible sum,
@@ -192,3 +210,100 @@ class Trainer:
         self.forward_backward(img, targets, lengths, keep_mask2)
         self.sam_second_step(lr)
         return loss
+
+
+class GraphedStep:
+    """Trainer.step as a replayed HIP graph.
+
+    What a graph bakes and what changes per step decides the layout: every per-step INPUT lives in a fixed device buffer
+    that the host refreshes in stream order before the replay -- the image batch (`img`; fill it in place or pass a
+    tensor to step(), copied device-to-device), the label arrays (`tg`, `tl`, `off`, sized for `max_target_len` labels
+    per line: the CTC kernels are launched for that bound), the span keep-mask (`keep`), and AdamW's derived scalars
+    (`hyper`: lr and the step number change every iteration, htrvt_adamw_dev reads them from device memory).  Host
+    staging goes through pinned buffers; before re-filling them the host waits for the previous step's copies, which
+    also bounds its run-ahead to one step (what Engine.forward's throttle does for the eager path)."""
+
+    def __init__(self, tr, img, max_target_len, masked=True):
+        import numpy as np
+        from ._lib import lib, HTRVT_ADAMW_SCALARS
+        self.tr, self.np = tr, np
+        eng, fl = tr.engine, tr.flat
+        if tr.step_count < 1:
+            raise RuntimeError("capture_step: run one eager step() of this batch shape first")
+        dev = img.device
+        B, N = img.shape[0], tr.model.num_patches
+        self.B, self.N, self.maxlen = B, N, int(max_target_len)
+        assert 1 <= self.maxlen
+        cap = B * self.maxlen
+        self.img = img.detach().clone().contiguous()
+        self.keep = torch.ones(N, dtype=torch.float32, device=dev) if masked else None
+        self.tg = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.tl = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.off = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.hyper = torch.zeros(HTRVT_ADAMW_SCALARS, dtype=torch.float32, device=dev)
+        self._h_tg = torch.zeros(cap, dtype=torch.int32).pin_memory()
+        self._h_tl = torch.zeros(B, dtype=torch.int32).pin_memory()
+        self._h_off = torch.zeros(B, dtype=torch.int32).pin_memory()
+        self._h_keep = torch.ones(N, dtype=torch.float32).pin_memory()
+        self._h_hyper = torch.zeros(HTRVT_ADAMW_SCALARS, dtype=torch.float32).pin_memory()
+        self._staged = None
+        fl.check_views()
+        mark_weights_dirty(tr.model)       # the recorded forward must contain the weight re-layout launch
+        self.graph = torch.cuda.CUDAGraph()
+        eng.capturing = True
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = tr._forward_backward_staged(self.img, (self.tg, self.tl, self.off, self.maxlen), self.keep)
+                from ._lib import check
+                from .ops import ptr, stream
+                check(lib.htrvt_adamw_dev(ptr(fl.flat_p), ptr(fl.flat_g), ptr(tr.flat_m), ptr(tr.flat_v), fl.flat_p.numel(),
+                                          ptr(self.hyper), stream()), "adamw_dev")
+        except BaseException:
+            # a refused capture leaves the engine mid-step: drop what it kept so that the eager path works again
+            eng._side_active, eng.saved, eng._zoff, eng._pending_unpack = False, None, None, []
+            raise
+        finally:
+            eng.capturing = False
+        mark_weights_dirty(tr.model)
+
+    def step(self, img, targets, lengths, keep_mask=None, lr=None):
+        """one replay; returns the (device, reused) mean-loss tensor of this step"""
+        from ._lib import lib
+        np, tr = self.np, self.tr
+        tr.flat.check_views()
+        if self._staged is not None:
+            self._staged.synchronize()      # previous step's host->device copies have run: the pinned buffers are free
+        tl = np.asarray(lengths, dtype=np.int32).reshape(-1)
+        tg = np.asarray(targets, dtype=np.int32).reshape(-1)
+        if tl.shape[0] != self.B or (tl.size and int(tl.max()) > self.maxlen) or tg.shape[0] > self._h_tg.numel():
+            raise ValueError(f"GraphedStep was captured for {self.B} lines of <= {self.maxlen} labels")
+        off = np.zeros_like(tl)
+        if tl.size > 1:
+            off[1:] = np.cumsum(tl[:-1])
+        self._h_tl.numpy()[:] = tl
+        self._h_off.numpy()[:] = off
+        self._h_tg.numpy()[:tg.shape[0]] = tg
+        for h, d in ((self._h_tg, self.tg), (self._h_tl, self.tl), (self._h_off, self.off)):
+            d.copy_(h, non_blocking=True)
+        if (keep_mask is None) != (self.keep is None):
+            raise ValueError("GraphedStep: captured with" + ("" if self.keep is not None else "out") + " a span mask")
+        if keep_mask is not None:
+            if keep_mask.is_cuda:
+                self.keep.copy_(keep_mask, non_blocking=True)
+            else:
+                self._h_keep.copy_(keep_mask.to(torch.float32).reshape(-1))
+                self.keep.copy_(self._h_keep, non_blocking=True)
+        if img is not self.img and img.data_ptr() != self.img.data_ptr():
+            self.img.copy_(img, non_blocking=True)
+        tr.step_count += 1
+        hy = self._h_hyper.numpy()
+        import ctypes
+        lib.htrvt_adamw_scalars(float(tr.lr if lr is None else lr), tr.betas[0], tr.betas[1], tr.eps, tr.wd, tr.step_count,
+                                ctypes.c_void_p(hy.ctypes.data))
+        self.hyper.copy_(self._h_hyper, non_blocking=True)
+        self._staged = torch.cuda.Event()
+        self._staged.record()
+        with trace.range_("htrvt.graph_step"):
+            self.graph.replay()
+        mark_weights_dirty(tr.model)
+        return self.loss

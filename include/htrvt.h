@@ -168,8 +168,8 @@ int htrvt_softmax_rows(const float* s, void* p, int64_t rows, int n, int dtype, 
  * probabilities stay on chip.  lse2 [B*heads][N] float32 (may be NULL in the forward when no backward follows):
  * log2 of the softmax denominator in the scaled base-2 domain, P = exp2(S * scale * log2(e) - lse2).
  * delta [B*heads][N] float32: scratch of the backward (rowsum(dout * out), written by its first launch).
- * htrvt_attn_supported: N a multiple of 128, hd in {32, 64, 128}, dtype bfloat16 (others: the htrvt_gemm +
- * htrvt_softmax_rows path).
+ * htrvt_attn_supported: any N >= 32 (partial last query / key tiles are masked inside the kernels), hd in {32, 64, 128},
+ * dtype bfloat16 (others: the htrvt_gemm + htrvt_softmax_rows path).
  * bias (may be NULL): float32 [heads][N][N] added to the scaled scores before the softmax -- the variant blocks of
  * relative-position bias table gathered per (query, key) and, for 1-D windowed / shifted attention, a
  * large negative number (-1e30, not -inf) outside the query's window (model_window/model/HTR_VT.py:23-56,113-154);
@@ -308,6 +308,13 @@ int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows,
  * Python, derived scalars (1 - lr*wd, 1 - beta, bias corrections, -lr/bc1) are formed in double and rounded once. */
 int htrvt_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                 double eps, double weight_decay, int step, void* stream);
+/* The same step with its derived scalars read from DEVICE memory: a captured HIP graph bakes kernel arguments, while lr
+ * (utils.update_lr_cos, train.py:115) and the step number change every iteration.  htrvt_adamw_scalars forms the
+ * HTRVT_ADAMW_SCALARS floats on the host exactly as htrvt_adamw does (same doubles, same single rounding), the caller
+ * copies them to `hyper_dev` in stream order before the launch / the graph replay: bit-identical to htrvt_adamw. */
+#define HTRVT_ADAMW_SCALARS 8
+int htrvt_adamw_scalars(double lr, double beta1, double beta2, double eps, double weight_decay, int step, float* out_host);
+int htrvt_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream);
 
 /* ---- around the path: SAM, EMA, greedy decode ---------------- */
 /* out[0] = sum x^2 (deterministic two-stage); partial: htrvt_sumsq_blocks(n) floats of scratch.  With x = the flat

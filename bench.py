@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "split_bf16": 2500.0}        # dense MFMA peaks, MI355X_MICROARCH.md (split: MFMA FLOPs = 3x algorithmic)
 
 
 def parse():
@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in total, split evenly over the ranks")
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "split_bf16"], help="bf16: the throughput path; f32 / split_bf16: the two parity paths (f32-input MFMA / hi+lo bf16 operands)")
     # model size: create_model's constants (HTR_VT.py:244-254) by default; BASELINE configs 1 / 5 name other sizes, which
     # the reference reaches through MaskedAutoencoderViT(...) directly (HTR_VT.py:143-151)
     ap.add_argument("--embed-dim", type=int, default=768)
@@ -68,8 +68,9 @@ def parse():
     ap.add_argument("--gemm-table", default=None, help="write the per-shape MFMA launch table (roofline leg) to this file")
     ap.add_argument("--traffic-json", default=None, help="PMC traffic summary (tools/collect_pmc.sh -> tools/pmc_summary.py) "
                     "the roofline's `traffic` is read from; default: the newest profiles/r*_pmc_traffic.json")
-    ap.add_argument("--graph", default="off", choices=["off", "on"], help="replay the training step as ONE captured HIP "
-                    "graph (Trainer.capture_step) inside the timed region instead of ~360 eager launches")
+    ap.add_argument("--graph", default="off", choices=["off", "on", "multi"], help="replay the training step as ONE captured HIP "
+                    "graph (Trainer.capture_step) inside the timed region instead of ~360 eager launches; on: captured on one "
+                    "stream, multi: with the eager step's side streams (weight gradients, weight packs)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the strong-scaling sub-record (global batch "
                     "128 split over the ranks, graph-replayed) that follows the timed weak-scaling steps")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -136,25 +137,32 @@ def cpu_baseline(args, mask):
 
 
 def parity_path(args, dev, x, tg, tl, keep):
-    """the same training step on the float32 parity path (f32-input MFMA, bitwise-reproducible reductions) -- the path
-    that meets the 1e-3 logit gate of BASELINE.json -- timed briefly beside the bf16 headline so that the driver's
-    record carries both; reported, not part of `value`"""
-    from htrvt_amd.model import HTR_VT
+    """the same training step on the two paths that meet BASELINE.json's 1e-3 logit gate, timed briefly beside the bf16
+    headline so that the driver's record carries them; reported, not part of `value`:
+      split_bf16 -- float32 activations, conv / Linear operands split into hi + lo bf16 parts on the bf16 matrix cores
+                    (three products, float32 accumulate; csrc/split.hip)
+      f32        -- f32-input MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate), bitwise-reproducible reductions"""
     from htrvt_amd.trainer import Trainer
-    torch.manual_seed(123)
-    model = build_model(args, torch.float32).to(dev).train()
-    tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=False)
-    steps = 3
-    tr.step(x, tg, tl, keep_mask=keep)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.step(x, tg, tl, keep_mask=keep)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"dtype": "f32", "ms_per_step": round(dt * 1e3, 2), "value": round(x.shape[0] / dt, 1), "unit": "line-images/s",
-            "steps": steps, "loss": float(loss.item()),
-            "note": "float32 parity path (logits within 1e-3 of the reference, tests/test_full_shape_gpu.py), same step and batch"}
+    out = {}
+    for tag, cd in (("split_bf16", "split_bf16"), ("f32", torch.float32)):
+        torch.manual_seed(123)
+        model = build_model(args, cd).to(dev).train()
+        tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=False)
+        steps = 3
+        tr.step(x, tg, tl, keep_mask=keep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(x, tg, tl, keep_mask=keep)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[tag] = {"ms_per_step": round(dt * 1e3, 2), "value": round(x.shape[0] / dt, 1), "unit": "line-images/s", "steps": steps,
+                    "loss": float(loss.item())}
+        del tr, model
+        torch.cuda.empty_cache()
+    best = out["split_bf16"]
+    return {"dtype": "split-bf16 (f32 activations, hi+lo bf16 MFMA operands)", **best, "f32_mfma": out["f32"],
+            "note": "paths whose logits are within 1e-3 of the reference (tests/test_full_shape_gpu.py), same step and batch"}
 
 
 def set_stem_fusion(eng, args):
@@ -203,19 +211,23 @@ def strong_leg(args, dev, world, rank, dtype, use_dist, steps=10, warmup=3):
     keep = model.generate_span_mask(N, 0.4, 8)
     tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=world, use_collectives=use_dist and world > 1)
     tr.step(x, tg, tl, keep_mask=keep)
-    graphed, note = True, None
-    try:
-        gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True)
+    # eager launches by default: on this runtime a replayed graph of the step is SLOWER than its ~360 eager launches (one
+    # MI355X, 16 images: 8.0 ms replayed from a one-stream capture, 14.3 ms from the four-stream capture, 6.9 ms eager --
+    # hipGraphLaunch spaces the kernel nodes further apart than back-to-back launches do)
+    graphed, note = args.graph != "off", None
 
-        def one():
-            return gs.step(gs.img, tg, tl, keep_mask=keep)
-    except Exception as e:      # noqa: BLE001 -- a refused capture (e.g. a collective that cannot be recorded) is reported, not fatal
-        graphed, note = False, f"graph capture refused ({type(e).__name__}: {str(e)[:120]}); eager launches"
+    def one():
+        return tr.step(x, tg, tl, keep_mask=keep)
+    if graphed:
+        try:
+            gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True, single_stream=args.graph == "on")
 
-        def one():
-            return tr.step(x, tg, tl, keep_mask=keep)
+            def one():       # noqa: F811
+                return gs.step(gs.img, tg, tl, keep_mask=keep)
+        except Exception as e:      # noqa: BLE001 -- a refused capture (e.g. a collective that cannot be recorded) is reported, not fatal
+            graphed, note = False, f"graph capture refused ({type(e).__name__}: {str(e)[:120]}); eager launches"
     # every rank takes the same branch: a refused capture on one rank would desynchronise the collectives
-    if use_dist:
+    if use_dist and args.graph != "off":
         flag = torch.tensor([1 if graphed else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if graphed and int(flag.item()) == 0:
@@ -293,7 +305,7 @@ def main():
     from htrvt_amd.model import HTR_VT
     from htrvt_amd.trainer import Trainer
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "split_bf16": "split_bf16"}[args.dtype]
     torch.manual_seed(123)                                                  # option.py default --seed 123
     model = build_model(args, dtype).to(dev)
     N = model.num_patches
@@ -339,9 +351,9 @@ def main():
                 ema.update(model, num_updates=it[0] / 2)
                 it[0] += 1
                 return l_
-        elif args.graph == "on":
+        elif args.graph != "off":
             tr.step(x, tg, tl, keep_mask=keep)          # lazily sized workspaces, one-time kernel attributes
-            gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True)
+            gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True, single_stream=args.graph == "on")
 
             def one_step():
                 return gs.step(gs.img, tg, tl, keep_mask=keep)
@@ -386,7 +398,7 @@ def main():
     if not args.forward_only:
         saved_overlap, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False   # one stream: events time ONE kernel
     # (a replayed graph has no per-launch events: the two profiled steps always run as eager launches)
-    prof_step = one_step if (args.forward_only or args.sam or args.graph != "on") else (lambda: tr.step(x, tg, tl, keep_mask=keep))
+    prof_step = one_step if (args.forward_only or args.sam or args.graph == "off") else (lambda: tr.step(x, tg, tl, keep_mask=keep))
     for _ in range(2):
         prof_step()
     torch.cuda.synchronize()
@@ -456,7 +468,7 @@ def main():
                           "tokens_per_image": N, "mask": "span 0.4/8 (run/iam.sh)", "parallelism": f"dp{world}",
                           "engine_flags": {k: getattr(eng_, k) for k in ("fuse_stem_forward", "fuse_bn_backward", "overlap_wgrad",
                                                                           "fused_attention", "deterministic", "parallel_classes")},
-                          "graph_replay": args.graph == "on" and not (args.forward_only or args.sam),
+                          "graph_replay": args.graph != "off" and not (args.forward_only or args.sam),
                           "loss": float(loss.mean().item()) if loss is not None else None},
                "roofline": roof}
         if strong is not None:

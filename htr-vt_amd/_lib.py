@@ -59,6 +59,7 @@ PROTOTYPES = {
     "htrvt_last_kernel": (C.c_char_p, []),
     "htrvt_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
+    "htrvt_gemm_wgrad_tiling": (i32, [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32)]),
     "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_stem_stats_rows": (i32, [i32, i32]),
@@ -104,6 +105,7 @@ PROTOTYPES = {
     "htrvt_relpos_bias_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_relpos_bias_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_cast_transpose_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "htrvt_split_bf16": (i32, [vp, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp]),
     "htrvt_sumsq_blocks": (i32, [i64]),
     "htrvt_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "htrvt_sam_first_step": (i32, [vp, vp, vp, i64, f32, vp, vp]),

@@ -1,11 +1,14 @@
 // gemm8p.hip -- host-side selection of the 8-phase bfloat16 GEMM kernels (gemm8p_impl.h; instantiated in
 // gemm8p_plain.hip / gemm8p_conv.hip).  Called by htrvt_gemm (gemm.hip) before the older LDS-DMA kernels.
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 using namespace htrvt;
 
 namespace htrvt {
 int gemm8p_dispatch_plain(int bn, int epi, const KParams&, int, hipStream_t);
+int gemm8pp_dispatch_plain(int bn, int epi, const KParams&, int nwg, hipStream_t);
 int gemm8p_dispatch_conv(int bn, int gather, int epi, const KParams&, int, hipStream_t);
 }  // namespace htrvt
 
@@ -40,8 +43,8 @@ namespace htrvt {
 // tile selector (HtrvtGemmDesc.tile): 0 auto, 9 this family (auto width), 10 / 11 this family with 256 / 192 columns;
 // 1..8 and BM*1000+BN keep meaning the older kernels
 int gemm8p_pick_bn(const HtrvtGemmDesc* d) {
-  if (d->tile == 10) return 256;
-  if (d->tile == 11) return 192;
+  if (d->tile == 10 || d->tile == 14) return 256;     // 13 / 14 / 15: the persistent form (auto width / 256 / 192 columns)
+  if (d->tile == 11 || d->tile == 15) return 192;
   // rounds of 256 workgroups x columns per tile; the 192-column tile costs ~12 % more per FLOP (12 instead of 16 MFMAs per
   // phase, 14 % more operand bytes per FLOP).  Measured (tools/bench_gemm.py --only enc --tiles 4 10 11, M = 32768):
   // N = 768 -> 192 (512 tiles = 2 full rounds; 256 columns: 384 tiles = 1.5), N = 2304 / 3072 -> 256
@@ -57,7 +60,7 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   // auto (tile 0): the Linear shapes only.  The implicit-GEMM convolutions stay on the loader-wave kernels of
   // gemm_dma_impl.h unless this family is asked for: with all eight waves forming gather addresses the k-tile is
   // 15-25 % slower there (tools/bench_gemm.py --only conv --tiles 4 10 11: layer-1 forward 969 vs 813 TFLOP/s)
-  if (!((d->tile == 0 && d->gather == HTRVT_GATHER_NONE) || (d->tile >= 9 && d->tile <= 11))) return false;
+  if (!((d->tile == 0 && d->gather == HTRVT_GATHER_NONE) || (d->tile >= 9 && d->tile <= 11) || (d->tile >= 13 && d->tile <= 15 && d->gather == HTRVT_GATHER_NONE))) return false;
   if (d->dtype != HTRVT_BF16 || d->M <= 128) return false;
   if (gemm_small_m_prefers_bn128(d)) return false;      // few rows, narrow N: more, narrower tiles (gemm_dma.hip pick_bn)
   if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
@@ -104,7 +107,32 @@ int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t 
       p.hwq_shift = b;
     }
   }
-  if (d->gather == HTRVT_GATHER_NONE) return gemm8p_dispatch_plain(bn, epi, p, zdim, st);
+  if (d->gather == HTRVT_GATHER_NONE) {
+    // Persistent walk (gemm8pp_impl.h): one workgroup per CU, the DMA stream and the k loop run through the tile boundaries,
+    // the epilogue of a tile is folded into the first k-tile of the next.  tile 0 (auto) and 13; 9-11 keep naming the
+    // one-tile-per-workgroup kernels (A/B runs, tests).  HTRVT_NO_PERSISTENT_GEMM=1 switches the auto route off.
+    static const bool off = getenv("HTRVT_NO_PERSISTENT_GEMM") != nullptr && getenv("HTRVT_NO_PERSISTENT_GEMM")[0] == '1';
+    const long long ntiles = (long long)p.tiles_m * p.tiles_n;
+    // auto: the plain / bias epilogue only.  With the GELU epilogue the folded flush is VALU-bound -- one wave per SIMD
+    // evaluates erf while its partner's 16 MFMAs are long done -- and measured 2-3 % SLOWER than the unfolded epilogue, in
+    // which both waves of a SIMD share the VALU (tools/bench_gemm.py --only enc --tiles 9 0: fc1 forward 830 vs 808 TFLOP/s)
+    const bool want = (d->tile >= 13 && d->tile <= 15) || (d->tile == 0 && !off && epi == 0);
+    if (want && (epi == 0 || epi == E_GELU) && zdim == 1 && d->batch <= 1 && d->K % 128 == 0 && d->K >= 256 &&
+        (reinterpret_cast<unsigned long long>(d->bias) & 15) == 0 && (d->preact == nullptr || (reinterpret_cast<unsigned long long>(d->preact) & 15) == 0)) {
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount & ~7;
+        if (ncu < 8) ncu = 256;
+      }
+      if (ntiles >= ncu) {
+        const int r = gemm8pp_dispatch_plain(bn, epi, p, ncu, st);
+        if (r != 0) return r;
+      }
+    }
+    return gemm8p_dispatch_plain(bn, epi, p, zdim, st);
+  }
   return gemm8p_dispatch_conv(bn, d->gather, epi, p, zdim, st);
 }
 

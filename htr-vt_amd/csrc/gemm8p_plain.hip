@@ -1,7 +1,7 @@
 // gemm8p_plain.hip -- instantiations of the 8-phase GEMM kernel for plain (Linear) operands: forward (bias, GELU +
 // saved pre-activation, residual) and dgrad against the transposed weight copy (plain, * GELU').  Own translation unit
 // (the Makefile builds the units in parallel).
-#include "gemm8p_impl.h"
+#include "gemm8pp_impl.h"
 
 namespace htrvt {
 
@@ -15,6 +15,19 @@ static int by_epi(int epi, const KParams& p, int zdim, hipStream_t st) {
     case E_GELUGRAD: return launch<C, 0, E_GELUGRAD>(p, zdim, st);
     default: return 0;
   }
+}
+
+// persistent form (gemm8pp_impl.h): bias / bias + GELU epilogues; nwg workgroups walk all tiles
+int gemm8pp_dispatch_plain(int bn, int epi, const KParams& p, int nwg, hipStream_t st) {
+  using namespace g8;
+  if (bn == 256) {
+    if (epi == 0) return launch_persistent<Cfg<256, 2, 4>, 0>(p, nwg, st);
+    if (epi == E_GELU) return launch_persistent<Cfg<256, 2, 4>, E_GELU>(p, nwg, st);
+  } else {
+    if (epi == 0) return launch_persistent<Cfg<192, 4, 2>, 0>(p, nwg, st);
+    if (epi == E_GELU) return launch_persistent<Cfg<192, 4, 2>, E_GELU>(p, nwg, st);
+  }
+  return 0;
 }
 
 int gemm8p_dispatch_plain(int bn, int epi, const KParams& p, int zdim, hipStream_t st) {

@@ -40,3 +40,12 @@ int gemm_hwgrad_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStre
 }
 
 }  // namespace htrvt
+
+// host query for the split-K heuristic of the caller: workgroups per K range, tile rows, tile columns of the launch the
+// halo-staged weight-gradient kernel would make for this descriptor; 0 when the generic kernels serve it
+extern "C" int htrvt_gemm_wgrad_tiling(const HtrvtGemmDesc* d, int* tile_rows, int* tile_cols) {
+  if (d == nullptr || !htrvt::gemm_hwgrad_serves(d)) return 0;
+  if (tile_rows) *tile_rows = 3 * htrvt::gemm_hwgrad_cc(d);
+  if (tile_cols) *tile_cols = htrvt::gemm_hwgrad_bn(d);
+  return htrvt::gemm_hwgrad_tiles(d);
+}

@@ -1,0 +1,131 @@
+// split.hip -- operands of the SPLIT-bfloat16 parity path (round 4).
+//
+// The float32 path meets BASELINE.json's 1e-3 logit gate on `v_mfma_f32_32x32x2_f32` at 1/16 of the bf16 matrix rate.
+// A float32 value is hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi), so
+//     x * w  =  x_hi w_hi + x_lo w_hi + x_hi w_lo  + O(2^-16 |x w|)
+// and the three products are ONE bf16 GEMM over a three times longer K when the operands are concatenated along K:
+//     A' = (x_hi | x_lo | x_hi),  B' = (w_hi | w_hi | w_lo)       (accumulated in float32 by the MFMA)
+// For an NHWC convolution "along K" is "along the channels" (3 Ci channels per pixel, weights packed accordingly); a
+// weight gradient contracts over pixels / rows instead and takes the hi and lo PLANES as three accumulating launches.
+// This kernel produces those forms from a float32 matrix; everything else on the parity path stays float32.
+#include "common.h"
+
+using namespace htrvt;
+
+namespace {
+
+constexpr int NT_ = 256;
+
+__device__ __forceinline__ void split1(float x, float& hi, float& lo) {
+  const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)x);      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  hi = __uint_as_float((unsigned)h << 16);
+  const float d = x - hi;                                                       // exact in float32 (|x - hi| <= half an ulp of hi)
+  const unsigned short l = __builtin_bit_cast(unsigned short, (__bf16)d);
+  lo = __uint_as_float((unsigned)l << 16);                                      // the bf16 value itself, also in the float32 copies
+}
+
+// vector form: cols % 8 == 0, rows of the outputs 16-byte aligned.  One thread = 8 consecutive columns of one row.
+// (first-class vector types and value selects only: arrays picked through a pointer, or HIP's struct uint4 under a
+// ternary, end up in scratch memory)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool F32OUT>
+__global__ __launch_bounds__(NT_) void split_rows_kernel(const float* __restrict__ src, long long rows, int cols, long long ld_src,
+                                                         void* __restrict__ cat, int order, bf16_t* __restrict__ hi_p,
+                                                         bf16_t* __restrict__ lo_p) {
+  const int cv = cols >> 3;
+  const long long total = rows * cv;
+  const bool o0 = order == 0;
+  for (long long t = (long long)blockIdx.x * NT_ + threadIdx.x; t < total; t += (long long)gridDim.x * NT_) {
+    const long long r = t / cv;
+    const int c = (int)(t - r * cv) * 8;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + r * ld_src + c);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + r * ld_src + c + 4);
+    f32x4_t ha, la, hb, lb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float h, l;
+      split1(a[e], h, l);
+      ha[e] = h; la[e] = l;
+      split1(b[e], h, l);
+      hb[e] = h; lb[e] = l;
+    }
+    if constexpr (F32OUT) {
+      float* o = reinterpret_cast<float*>(cat) + r * 3 * cols + c;
+      *reinterpret_cast<f32x4_t*>(o) = ha;
+      *reinterpret_cast<f32x4_t*>(o + 4) = hb;
+      *reinterpret_cast<f32x4_t*>(o + cols) = o0 ? la : ha;
+      *reinterpret_cast<f32x4_t*>(o + cols + 4) = o0 ? lb : hb;
+      *reinterpret_cast<f32x4_t*>(o + 2 * cols) = o0 ? ha : la;
+      *reinterpret_cast<f32x4_t*>(o + 2 * cols + 4) = o0 ? hb : lb;
+    } else {
+      const u32x4_t hv = {pack_bf16x2(ha[0], ha[1]), pack_bf16x2(ha[2], ha[3]), pack_bf16x2(hb[0], hb[1]), pack_bf16x2(hb[2], hb[3])};
+      const u32x4_t lv = {pack_bf16x2(la[0], la[1]), pack_bf16x2(la[2], la[3]), pack_bf16x2(lb[0], lb[1]), pack_bf16x2(lb[2], lb[3])};
+      if (cat != nullptr) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(cat) + r * 3 * cols + c;
+        *reinterpret_cast<u32x4_t*>(o) = hv;
+        *reinterpret_cast<u32x4_t*>(o + cols) = o0 ? lv : hv;
+        *reinterpret_cast<u32x4_t*>(o + 2 * cols) = o0 ? hv : lv;
+      }
+      if (hi_p != nullptr) *reinterpret_cast<u32x4_t*>(hi_p + r * cols + c) = hv;
+      if (lo_p != nullptr) *reinterpret_cast<u32x4_t*>(lo_p + r * cols + c) = lv;
+    }
+  }
+}
+
+// any shape (weights: small), optionally transposed: cat_t [cols][3 * rows] with block j of row c = part j of src[:, c]
+template <bool F32OUT>
+__global__ __launch_bounds__(NT_) void split_any_kernel(const float* __restrict__ src, long long rows, int cols, long long ld_src,
+                                                        void* __restrict__ cat, int order, int transpose) {
+  const long long total = rows * cols;
+  for (long long t = (long long)blockIdx.x * NT_ + threadIdx.x; t < total; t += (long long)gridDim.x * NT_) {
+    const long long r = t / cols;
+    const int c = (int)(t - r * cols);
+    float h, l;
+    split1(src[r * ld_src + c], h, l);
+    const float s[3] = {h, order == 0 ? l : h, order == 0 ? h : l};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long long o = transpose ? (long long)c * 3 * rows + j * rows + r : r * 3 * cols + (long long)j * cols + c;
+      if constexpr (F32OUT)
+        reinterpret_cast<float*>(cat)[o] = s[j];
+      else
+        reinterpret_cast<bf16_t*>(cat)[o] = from_f32<bf16_t>(s[j]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int htrvt_split_bf16(const float* src, int64_t rows, int cols, int64_t ld_src, void* cat, int order, int cat_f32,
+                                int transpose, void* hi, void* lo, void* stream) {
+  HTRVT_REQUIRE(src != nullptr && rows > 0 && cols > 0 && ld_src >= cols, "htrvt_split_bf16: bad source");
+  HTRVT_REQUIRE(order == 0 || order == 1, "htrvt_split_bf16: order 0 = (hi, lo, hi), 1 = (hi, hi, lo)");
+  HTRVT_REQUIRE(cat != nullptr || hi != nullptr || lo != nullptr, "htrvt_split_bf16: no output");
+  HTRVT_REQUIRE(!(transpose || cat_f32) || (hi == nullptr && lo == nullptr && cat != nullptr),
+                "htrvt_split_bf16: transposed / float32 outputs have the concatenated form only");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = !transpose && (cols % 8 == 0) && (ld_src % 4 == 0) && ((reinterpret_cast<unsigned long long>(src) & 15) == 0) &&
+                   ((reinterpret_cast<unsigned long long>(cat) & 15) == 0) && ((reinterpret_cast<unsigned long long>(hi) & 15) == 0) &&
+                   ((reinterpret_cast<unsigned long long>(lo) & 15) == 0);
+  if (vec) {
+    const long long total = (long long)rows * (cols / 8);
+    const unsigned grid = (unsigned)((total + NT_ - 1) / NT_ > 65536 * 4 ? 65536 * 4 : (total + NT_ - 1) / NT_);
+    if (cat_f32)
+      hipLaunchKernelGGL(split_rows_kernel<true>, dim3(grid), dim3(NT_), 0, st, src, (long long)rows, cols, (long long)ld_src, cat, order,
+                         (bf16_t*)nullptr, (bf16_t*)nullptr);
+    else
+      hipLaunchKernelGGL(split_rows_kernel<false>, dim3(grid), dim3(NT_), 0, st, src, (long long)rows, cols, (long long)ld_src, cat, order,
+                         (bf16_t*)hi, (bf16_t*)lo);
+    return check_launch("split_bf16");
+  }
+  HTRVT_REQUIRE(hi == nullptr && lo == nullptr, "htrvt_split_bf16: hi / lo planes need cols %% 8 == 0 and 16-byte aligned buffers");
+  const long long total = (long long)rows * cols;
+  const unsigned grid = (unsigned)((total + NT_ - 1) / NT_ > 65536 ? 65536 : (total + NT_ - 1) / NT_);
+  if (cat_f32)
+    hipLaunchKernelGGL(split_any_kernel<true>, dim3(grid), dim3(NT_), 0, st, src, (long long)rows, cols, (long long)ld_src, cat, order, transpose);
+  else
+    hipLaunchKernelGGL(split_any_kernel<false>, dim3(grid), dim3(NT_), 0, st, src, (long long)rows, cols, (long long)ld_src, cat, order, transpose);
+  return check_launch("split_bf16");
+}

@@ -72,11 +72,19 @@ def _job(kind, src, dst0, dst1, d0, d1, taps=0, cpad_in=0, cpad_out=0, row_taps=
 
 
 class Engine:
-    def __init__(self, shape: ModelShape, dtype=torch.float32, device="cuda"):
+    def __init__(self, shape: ModelShape, dtype=torch.float32, device="cuda", split_bf16=False):
         self.s = shape
         self.dtype = dtype
         self.dev = torch.device(device)
         self.dti = dt(dtype)
+        # Split-bfloat16 parity path (csrc/split.hip): activations, statistics and every non-GEMM kernel stay float32 exactly
+        # as on the float32 path; the convolutions and the encoder's Linear layers -- 98 % of the FLOPs -- run on the bf16
+        # matrix cores with operands split into hi + lo bf16 parts concatenated along K (three products, float32
+        # accumulate).  `gdt` is the element type the big GEMMs' operands have.
+        self.split = bool(split_bf16)
+        assert not self.split or dtype == torch.float32, "split_bf16 is a mode of the float32 path"
+        self.gdt = torch.bfloat16 if self.split else dtype
+        self._split_cache = []       # backward: the few most recent (source tensor, cat, hi, lo) splits (a gradient feeds dgrad AND wgrad)
         self._packs = {}      # name -> (version key, tensors)
         self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
         self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
@@ -115,6 +123,10 @@ class Engine:
         self._side, self._side_active = None, False
         self._call_started = None      # event at the start of the previous forward() (host run-ahead throttle)
         self.capturing = False         # True while Trainer.capture_step records the step into a HIP graph
+        # every launch of a step on ONE stream (no weight-gradient / weight-pack side streams): what a captured graph wants
+        # on this runtime -- hipGraphLaunch resolves cross-stream edges of a multi-stream capture node by node (measured: a
+        # graph of the four-stream step replays SLOWER than the eager launches, 14.3 vs 6.9 ms at 16 images)
+        self.single_stream = False
         self.saved = None
         self._bn_train = True
         self._zarena, self._zoff, self._zneed, self._zneed_max = None, None, 0, 0
@@ -159,9 +171,67 @@ class Engine:
     def _wkey(self, t):
         return (t.data_ptr(), t._version, self.weights_epoch)
 
+    # ------------------------------------------------------------------ split-bf16 operands (csrc/split.hip)
+    def _split(self, src, rows, cols, order=0, cat=True, planes=False, cat_f32=False, transpose=False):
+        """float32 [rows][cols] (contiguous) -> (cat [rows][3 cols] | transposed [cols][3 rows], hi, lo)"""
+        BF = torch.bfloat16
+        c = None
+        if cat:
+            shp = (cols, 3 * rows) if transpose else (rows, 3 * cols)
+            c = torch.empty(*shp, dtype=torch.float32 if cat_f32 else BF, device=self.dev)
+        hi = torch.empty(rows, cols, dtype=BF, device=self.dev) if planes else None
+        lo = torch.empty(rows, cols, dtype=BF, device=self.dev) if planes else None
+        check(lib.htrvt_split_bf16(ptr(src), rows, cols, cols, ptr(c), order, 1 if cat_f32 else 0, 1 if transpose else 0,
+                                   ptr(hi), ptr(lo), stream()), "split_bf16")
+        return c, hi, lo
+
+    def _split_act(self, t, cols, cat=True, planes=False):
+        """split of an activation / gradient tensor whose innermost extent is `cols`, remembered while the backward may ask
+        for it again (the same gradient is the A operand of a dgrad launch and the B operand of three wgrad launches)"""
+        for ent in self._split_cache:
+            if ent[0] is t and (ent[1] is not None or not cat) and (ent[2] is not None or not planes):
+                return ent[1], ent[2], ent[3]
+        c, hi, lo = self._split(t, t.numel() // cols, cols, order=0, cat=cat, planes=planes)
+        self._split_cache = [e for e in self._split_cache if e[0] is not t][-2:] + [(t, c, hi, lo)]
+        return c, hi, lo
+
+    def _lin_w_split(self, name, w):
+        """([out][3 in] (hi | hi | lo) for the forward, [in][3 out] of the transposed weight for the dgrad)"""
+        key = self._wkey(w)
+        ent = self._packs.get(name + "/split")
+        if ent is None or ent[0] != key:
+            out_f, in_f = w.shape
+            ws, _, _ = self._split(w, out_f, in_f, order=1)
+            wts, _, _ = self._split(w, out_f, in_f, order=1, transpose=True)
+            self._packs[name + "/split"] = (key, (ws, wts))
+            return ws, wts
+        return ent[1]
+
+    def _conv_w_split(self, name, w):
+        """forward pack [Co][taps][Cpad(3 Ci)] and dgrad pack [Ci][taps][Cpad(3 Co)] of the split weight: the conv as seen by
+        the bf16 kernels has 3 Ci input channels (hi | hi | lo copies of the weight against (hi | lo | hi) activations)"""
+        key = self._wkey(w)
+        ent = self._packs.get(name + "/split")
+        if ent is None or ent[0] != key:
+            Co, Ci, kh, kw = w.shape
+            taps = kh * kw
+            BF = torch.bfloat16
+            cpi3, cpo3 = cpad(3 * Ci, BF), cpad(3 * Co, BF)
+            fwd = torch.zeros(Co, taps, cpi3, dtype=BF, device=self.dev)
+            dgr = torch.zeros(Ci, taps, cpo3, dtype=BF, device=self.dev)
+            v, _, _ = self._split(w, Co, Ci * taps, order=1, cat_f32=True)          # [Co][3][Ci][taps] = a [Co, 3 Ci, kh, kw] weight
+            check(lib.htrvt_pack_conv_weight(ptr(v), ptr(fwd), None, Co, 3 * Ci, taps, cpi3, cpad(Co, BF), dt(BF), stream()), "pack_conv_weight")
+            v, _, _ = self._split(w, 1, Co * Ci * taps, order=1, cat_f32=True)      # [3][Co][Ci][taps] = a [3 Co, Ci, kh, kw] weight
+            check(lib.htrvt_pack_conv_weight(ptr(v), None, ptr(dgr), 3 * Co, Ci, taps, cpad(Ci, BF), cpo3, dt(BF), stream()), "pack_conv_weight")
+            self._packs[name + "/split"] = (key, (fwd, dgr))
+            return fwd, dgr
+        return ent[1]
+
     def _lin_w(self, name, w):
         """(weight, transposed weight) of a Linear in compute dtype: [out,in] for the forward GEMM and [in,out] for the
         dgrad GEMM dx = dy @ w, so that both are K-major x K-major products on the same kernel.  float32: (w, None)."""
+        if self.split:
+            return self._lin_w_split(name, w)
         if self.dtype == torch.float32:
             return w, None
         key = self._wkey(w)
@@ -197,6 +267,8 @@ class Engine:
 
     def _conv_w(self, name, w):
         """(fwd pack [Co][taps][Cpad_i], dgrad pack [Ci][taps][Cpad_o]) of a conv weight [Co,Ci,k,k]."""
+        if self.split:
+            return self._conv_w_split(name, w)
         key = self._wkey(w)
         ent = self._packs.get(name)
         Co, Ci, kh, kw = w.shape
@@ -237,15 +309,27 @@ class Engine:
     def linear_fwd(self, x, w, bias, out=None, act=0, preact=None, residual=None, c_f32=False):
         M, K = x.shape
         N = w.shape[0]
+        if self.split:      # w = (hi | hi | lo) [N][3 K]; float32 in, float32 out, the epilogue's side tensors float32
+            out = self._empty(M, N) if out is None else out
+            xs, _, _ = self._split_act(x, K)
+            gemm(xs, w, out, dtype=self.gdt, M=M, N=N, K=3 * K, lda=3 * K, ldb=3 * K, ldc=N, bias=bias, act=act, preact=preact,
+                 residual=residual, c_f32=True)
+            return out
         if out is None:
             out = self._empty(M, N, dtype=torch.float32 if c_f32 else self.dtype)
         gemm(x, w, out, dtype=self.dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, preact=preact,
              residual=residual, c_f32=c_f32)
         return out
 
-    def linear_dgrad(self, dy, w, wt=None, act=0, preact=None):
+    def linear_dgrad(self, dy, w, wt=None, act=0, preact=None, plain=False):
         """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(preact)).  wt = w^T [K][>=N] (bf16 path): K-major B operand."""
         M, N = dy.shape
+        if self.split and not plain:      # wt = (hi | hi | lo) of w^T: [K][3 N]
+            K = wt.shape[0]
+            dx = self._empty(M, K)
+            dys, _, _ = self._split_act(dy, N, cat=True, planes=True)
+            gemm(dys, wt, dx, dtype=self.gdt, M=M, N=K, K=3 * N, lda=3 * N, ldb=3 * N, ldc=K, act=act, preact=preact, c_f32=True)
+            return dx
         K = w.shape[1]
         dx = self._empty(M, K)
         if wt is not None:
@@ -255,22 +339,29 @@ class Engine:
         return dx
 
     def _hwgrad_tiles(self, g):
-        """output tiles per pixel range of the halo-staged conv weight-gradient kernel (csrc/gemm_hwgrad.hip: 3x3, stride 1,
-        row length a multiple of 64), or None where the generic kernel serves the convolution"""
-        if self.dtype != torch.bfloat16 or not self.halo_wgrad:
+        """(workgroups per pixel range, tile rows, tile columns) of the halo-staged conv weight-gradient kernel, asked of the
+        library itself (htrvt_gemm_wgrad_tiling: the same eligibility test htrvt_gemm applies), or None where the generic
+        kernel serves the convolution"""
+        if self.gdt != torch.bfloat16 or not self.halo_wgrad:
             return None
-        if (g.kh, g.kw, g.sw, g.ph, g.pw) != (3, 3, 1, 1, 1) or g.sh not in (1, 2) or g.Wi % 64:
-            return None
-        cp = cpad(g.Ci, self.dtype)
-        cc = 128 if cp % 128 == 0 else 64
-        bn = 192 if (g.Co + 191) // 192 * 192 <= (g.Co + 127) // 128 * 128 else 128
-        return 3 * (cp // cc) * ((g.Co + bn - 1) // bn), 3 * cc, bn
+        import ctypes
+        from ._lib import GemmDesc
+        d = GemmDesc()
+        cp = cpad(g.Ci, self.gdt)
+        d.dtype, d.a_layout, d.b_layout, d.gather = dt(self.gdt), MNMAJOR, MNMAJOR, GATHER_CONV_WGRAD
+        d.M, d.N, d.K = g.taps * cp, g.Co, g.B * g.Ho * g.Wo
+        d.lda, d.ldb, d.ldc = g.Ci, g.Co, g.Co
+        g.fill(d)
+        d.Cpad, d.c_f32, d.accumulate, d.batch = cp, 1, 1, 1
+        tr, tc = ctypes.c_int32(0), ctypes.c_int32(0)
+        n = lib.htrvt_gemm_wgrad_tiling(ctypes.byref(d), ctypes.byref(tr), ctypes.byref(tc))
+        return (n, tr.value, tc.value) if n > 0 else None
 
     def _split_k(self, Mo, No, Kred, conv=False, tiling=None):
         """split-K factor of a weight-gradient GEMM: fill the 256 CUs in whole rounds, but keep the float32
         atomic traffic (one full output tile per block, ~1.3 TB/s chip-wide) small against the MFMA time."""
-        bm, bn = (256, 192) if self.dtype == torch.bfloat16 else (128, 128)
-        if conv and self.dtype == torch.bfloat16 and No % 256 == 0:
+        bm, bn = (256, 192) if self.gdt == torch.bfloat16 else (128, 128)
+        if conv and self.gdt == torch.bfloat16 and No % 256 == 0:
             bn = 256      # gemm_dma.hip pick_bn(): conv weight gradients with N % 256 == 0 use 256x256 tiles
         tiles = ((Mo + bm - 1) // bm) * ((No + bn - 1) // bn)
         if tiling is not None:
@@ -292,7 +383,14 @@ class Engine:
         return best
 
     def _splitk_ws(self, sk, Mo, No):
-        if sk <= 1 or not self.deterministic or No % 4:
+        if sk > 1 and self.deterministic and No % 4:
+            if not getattr(self, "_warned_atomics", False):     # slabs need 16-byte rows: this launch falls back to float atomics
+                import warnings
+                warnings.warn(f"htrvt_amd: split-K weight gradient with {No} output columns (not a multiple of 4) uses float "
+                              "atomics: results are not bitwise reproducible although Engine.deterministic is set")
+                self._warned_atomics = True
+            return None
+        if sk <= 1 or not self.deterministic:
             return None
         return self._empty(sk, Mo, No, dtype=torch.float32)
 
@@ -317,17 +415,26 @@ class Engine:
         if self._side is not None and self._side_active:
             torch.cuda.current_stream().wait_stream(self._side)
 
-    def linear_wgrad(self, dy, x, dw, dbias):
-        return self._on_side(lambda: self._linear_wgrad(dy, x, dw, dbias), dy, x)
+    def linear_wgrad(self, dy, x, dw, dbias, plain=False):
+        return self._on_side(lambda: self._linear_wgrad(dy, x, dw, dbias, plain), dy, x)
 
     def conv_wgrad(self, dy, x, g, dw):
         return self._on_side(lambda: self._conv_wgrad(dy, x, g, dw), dy, x)
 
-    def _linear_wgrad(self, dy, x, dw, dbias):
+    def _linear_wgrad(self, dy, x, dw, dbias, plain=False):
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
         M, N = dy.shape
         K = x.shape[1]
         sk = self._split_k(N, K, M)
+        if self.split and not plain:      # the contraction runs over the rows: hi / lo planes, three accumulating launches
+            _, dyh, dyl = self._split_act(dy, N, cat=False, planes=True)
+            _, xh, xl = self._split_act(x, K, cat=False, planes=True)
+            for a_, b_ in ((dyh, xh), (dyh, xl), (dyl, xh)):
+                gemm(a_, b_, dw, dtype=self.gdt, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
+                     split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, N, K))
+            if dbias is not None:
+                ops.colsum(dy, M, N, N, dbias, dti=self.dti)
+            return
         gemm(dy, x, dw, dtype=self.dtype, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
              split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, N, K))
         if dbias is not None:
@@ -342,11 +449,18 @@ class Engine:
         y = self._empty(g.B, g.Ho, g.Wo, g.Co)
         cs, rows = None, 0
         if want_stats:
-            rows = ops.gemm_num_mtiles(M, g.Co, self.dtype, gather=GATHER_CONV_FWD)
+            rows = ops.gemm_num_mtiles(M, g.Co, self.gdt, gather=GATHER_CONV_FWD)
             cs = self._empty(rows + 64, 2, g.Co, dtype=torch.float32)
         kw = {}
         if bn is not None:
             kw = dict(colscale=bn[0], bias=bn[1], residual=residual, act=3 if relu else 0)
+        if self.split:      # the same convolution over 3 Ci input channels: (hi | lo | hi) pixels against the (hi | hi | lo) pack
+            x3, _, _ = self._split_act(x, g.Ci)
+            g3 = ConvGeom(g.B, g.Hi, g.Wi, 3 * g.Ci, g.Co, g.kh, (g.sh, g.sw), g.ph)
+            cp3 = cpad(3 * g.Ci, self.gdt)
+            gemm(x3, wf, y, dtype=self.gdt, M=M, N=g.Co, K=g.taps * cp3, lda=3 * g.Ci, ldb=g.taps * cp3, ldc=g.Co,
+                 gather=GATHER_CONV_FWD, geom=g3, Cpad=cp3, colstats=cs, c_f32=True, **kw)
+            return y, cs, rows
         gemm(x, wf, y, dtype=self.dtype, M=M, N=g.Co, K=g.taps * cpi, lda=g.Ci, ldb=g.taps * cpi, ldc=g.Co,
              gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs, **kw)
         return y, cs, rows
@@ -397,18 +511,33 @@ class Engine:
             for st_ in used:       # every class has written its pixels before anything downstream reads dx
                 main.wait_stream(st_)
             return dx
+        if self.split:      # 3 Co gradient channels: (hi | lo | hi) against the (hi | hi | lo) dgrad pack
+            assert relu_src is None and bnb is None and relu_bn is None
+            dy3, _, _ = self._split_act(dy, g.Co, cat=True, planes=True)
+            g3 = ConvGeom(g.B, g.Hi, g.Wi, g.Ci, 3 * g.Co, g.kh, (g.sh, g.sw), g.ph)
+            cp3 = cpad(3 * g.Co, self.gdt)
+            gemm(dy3, wd, dx, dtype=self.gdt, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cp3, lda=3 * g.Co, ldb=g.taps * cp3,
+                 ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g3, Cpad=cp3, residual=residual, c_f32=True)
+            return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb, relu_bn=relu_bn)
         return dx
 
     def _conv_wgrad(self, dy, x, g: ConvGeom, dw):
         M = g.B * g.Ho * g.Wo
-        cpi = cpad(g.Ci, self.dtype)
+        cpi = cpad(g.Ci, self.gdt)
         packed = self._zeros(g.taps, cpi, g.Co)
         sk = self._split_k(g.taps * cpi, g.Co, M, conv=True, tiling=self._hwgrad_tiles(g))
-        gemm(x, dy, packed, dtype=self.dtype, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
-             a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
-             split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, g.taps * cpi, g.Co))
+        if self.split:      # the contraction runs over the pixels: hi / lo planes, three accumulating launches
+            _, xh, xl = self._split_act(x, g.Ci, cat=False, planes=True)
+            _, dyh, dyl = self._split_act(dy, g.Co, cat=False, planes=True)
+            pairs = ((xh, dyh), (xl, dyh), (xh, dyl))
+        else:
+            pairs = ((x, dy),)
+        for x_, dy_ in pairs:
+            gemm(x_, dy_, packed, dtype=self.gdt, M=g.taps * cpi, N=g.Co, K=M, lda=g.Ci, ldb=g.Co, ldc=g.Co,
+                 a_layout=MNMAJOR, b_layout=MNMAJOR, gather=GATHER_CONV_WGRAD, geom=g, Cpad=cpi,
+                 split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, g.taps * cpi, g.Co))
         if self.table_relayout and self._zoff is not None:    # inside backward(): unpacked with its DP bucket, one launch
             self._pending_unpack.append((packed, dw, g.Co, g.Ci, g.taps, cpi))
         else:
@@ -601,6 +730,7 @@ class Engine:
             self._call_started.record()
         st = stream()
         sv = {} if save else None
+        self._split_cache = []
         C1 = s.D // 4
         keep = None
         if keep_mask is not None:   # uploaded before anything is enqueued: a pageable host->device copy waits for the stream
@@ -609,7 +739,9 @@ class Engine:
                 keep = keep.pin_memory().to(self.dev, non_blocking=True)
 
         prefetched = False
-        if self.prefetch_packs and self.dtype == torch.bfloat16:
+        if self.prefetch_packs and self.dtype == torch.bfloat16 and self.single_stream:
+            self._repack_all(P, save) if self.table_relayout else None
+        elif self.prefetch_packs and self.dtype == torch.bfloat16:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
             self._side.wait_stream(torch.cuda.current_stream())     # behind whatever wrote the weights (the optimizer step)
@@ -821,7 +953,7 @@ class Engine:
         self._pending_unpack = []
         self._bn_train = bool(sv["train"])
         assert dy.dtype == torch.float32 and dy.shape == (B, N, C)
-        self._side_active = self.overlap_wgrad
+        self._side_active = self.overlap_wgrad and not self.single_stream
 
         # sequence LN, head, final norm
         Cp = (C + 7) // 8 * 8           # class dim padded so that every 16-byte chunk is aligned
@@ -829,12 +961,12 @@ class Engine:
         check(lib.htrvt_seq_whiten_bwd(ptr(dy), ptr(sv["y"]), ptr(sv["sstats"]), ptr(draw), B, N, C, Cp, self.dti, st),
               "seq_whiten_bwd")
         wh, wht = self._head_w(P["head.weight"])
-        dxn = self.linear_dgrad(draw, wh, wht)
+        dxn = self.linear_dgrad(draw, wh, wht, plain=True)      # (split mode: the 80-class head stays on the float32 kernels)
         if Cp == C:
-            self.linear_wgrad(draw, sv["xn"], G["head.weight"], G["head.bias"])
+            self.linear_wgrad(draw, sv["xn"], G["head.weight"], G["head.bias"], plain=True)
         else:
             dwp, dbp = self._zeros(Cp, D), self._zeros(Cp)
-            self.linear_wgrad(draw, sv["xn"], dwp, dbp)
+            self.linear_wgrad(draw, sv["xn"], dwp, dbp, plain=True)
             self._join_side()
             check(lib.htrvt_rowsum_f32(ptr(dwp), 1, C * D, ptr(G["head.weight"]), st), "rowsum")
             check(lib.htrvt_rowsum_f32(ptr(dbp), 1, C, ptr(G["head.bias"]), st), "rowsum")
@@ -917,7 +1049,8 @@ class Engine:
                 parts_d = parts[1] if len(parts) > 1 else None
             # downsample gradient as one more tap of the strided conv's class-(0,0) dgrad: d(conv1 out) and d(downsample
             # out) then live back to back in one allocation (the second gather source sits at a fixed offset from the first)
-            fuse_ds = self.fuse_downsample_dgrad and blk["gd"] is not None and self._dgrad_by_class(blk["g1"])
+            fuse_ds = (self.fuse_downsample_dgrad and blk["gd"] is not None and self._dgrad_by_class(blk["g1"]) and
+                       2 * blk["ca"].numel() * blk["ca"].element_size() < 2 ** 31 - 64)     # A2 lies behind A inside ONE 2 GiB descriptor
             pair = self._empty(2, *blk["ca"].shape) if fuse_ds else None
             dca_out = pair[0] if fuse_ds else None
             dcd = None
@@ -1009,4 +1142,5 @@ class Engine:
         self._join_side()
         self._side_active = False
         self._zarena_end()
+        self._split_cache = []
         self.saved = None

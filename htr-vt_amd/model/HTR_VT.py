@@ -143,7 +143,7 @@ class MaskedAutoencoderViT(nn.Module):
         eps = {m.eps for m in self.modules() if isinstance(m, nn.LayerNorm)}
         assert len(eps) == 1, f"one LayerNorm eps per model expected, got {eps}"
         self._shape = ModelShape(nb_cls, img_size, embed_dim, depth, num_heads, mlp_ratio, patch_size, ln_eps=eps.pop())
-        self.compute_dtype = compute_dtype          # torch.float32 (parity) or torch.bfloat16 (throughput)
+        self.compute_dtype = compute_dtype          # torch.float32 (parity), "split_bf16" (parity on the bf16 matrix cores) or torch.bfloat16 (throughput)
         self._engines = {}
 
     def initialize_weights(self):
@@ -170,7 +170,10 @@ class MaskedAutoencoderViT(nn.Module):
     def _engine(self, device):
         key = (str(device), self.compute_dtype)
         if key not in self._engines:
-            self._engines[key] = Engine(self._shape, self.compute_dtype, device)
+            if self.compute_dtype == "split_bf16":      # float32 activations, hi + lo bf16 operands on the matrix cores (csrc/split.hip)
+                self._engines[key] = Engine(self._shape, torch.float32, device, split_bf16=True)
+            else:
+                self._engines[key] = Engine(self._shape, self.compute_dtype, device)
         return self._engines[key]
 
     def generate_span_mask(self, x, mask_ratio, max_span_length):

@@ -167,13 +167,13 @@ class Trainer:
         self.optimizer_step(lr)
         return loss
 
-    def capture_step(self, img, max_target_len, masked=True):
+    def capture_step(self, img, max_target_len, masked=True, single_stream=True):
         """Record step() -- gradient clear, forward, CTC, backward (incl. the bucketed all-reduces when a process group
         is in use), AdamW -- into ONE HIP graph (~360 launches per step are launch-bound at small per-rank
         batches).  Call after at least one eager step() of the same batch shape (lazily sized workspaces, one-time
         kernel attributes and the engine's streams exist then).  Returns a GraphedStep; its step() has step()'s
         signature and results (bit-identical: same kernels, same order, same scalars)."""
-        return GraphedStep(self, img, max_target_len, masked)
+        return GraphedStep(self, img, max_target_len, masked, single_stream)
 
     def sam_first_step(self, rho=0.05):
         """SAM.first_step (utils/sam.py:15-27, adaptive=False) on the flat buffers: |g| by a two-stage reproducible sum,
@@ -223,7 +223,7 @@ class GraphedStep:
     staging goes through pinned buffers; before re-filling them the host waits for the previous step's copies, which
     also bounds its run-ahead to one step (what Engine.forward's throttle does for the eager path)."""
 
-    def __init__(self, tr, img, max_target_len, masked=True):
+    def __init__(self, tr, img, max_target_len, masked=True, single_stream=True):
         import numpy as np
         from ._lib import lib, HTRVT_ADAMW_SCALARS
         self.tr, self.np = tr, np
@@ -251,6 +251,7 @@ class GraphedStep:
         mark_weights_dirty(tr.model)       # the recorded forward must contain the weight re-layout launch
         self.graph = torch.cuda.CUDAGraph()
         eng.capturing = True
+        saved_single, eng.single_stream = eng.single_stream, bool(single_stream)
         try:
             with torch.cuda.graph(self.graph):
                 self.loss = tr._forward_backward_staged(self.img, (self.tg, self.tl, self.off, self.maxlen), self.keep)
@@ -264,6 +265,7 @@ class GraphedStep:
             raise
         finally:
             eng.capturing = False
+            eng.single_stream = saved_single
         mark_weights_dirty(tr.model)
 
     def step(self, img, targets, lengths, keep_mask=None, lr=None):

@@ -112,6 +112,11 @@ typedef struct HtrvtGemmDesc {
 int htrvt_gemm(const HtrvtGemmDesc* d, void* stream);
 /* rows of colstats (= number of M tiles) the call above will write for this desc */
 int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d);
+/* Weight-gradient launches (gather = HTRVT_GATHER_CONV_WGRAD): which tiling htrvt_gemm would use.  Returns the number of
+ * workgroups per K range and the tile extents when the halo-staged kernel (3x3, W stride 1, row length a multiple of 64,
+ * Cpad a multiple of 64, float32 output, operands inside 2 GiB) serves the descriptor, 0 when the generic kernels do: the
+ * caller's split-K choice must count the workgroups of the kernel that actually runs. */
+int htrvt_gemm_wgrad_tiling(const HtrvtGemmDesc* d, int* tile_rows, int* tile_cols);
 
 /* ---- stem helpers (resnet18.py:42-84, HTR_VT.py:134-136,224-227) ------------- */
 /* per-image mean / rstd of the raw image (param-free LayerNorm, eps 1e-5): stats[b] = {mean, rstd}.
@@ -302,6 +307,19 @@ int htrvt_relayout_host(const HtrvtRelayoutJob* jobs_host, int njobs, int total_
  * `dtype` (bfloat16), columns rows .. ld_t-1 of dst_t zero: the K-major B operand of the Linear dgrad GEMM
  * dx[M][in] = dy[M][out] * w (HTR_VT.py:22-37 backward), so that forward and dgrad run the same kernel. */
 int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows, int cols, int ld_t, int dtype, void* stream);
+
+/* ---- split-bfloat16 operands of the parity path (csrc/split.hip) -----------------------------------------------------
+ * x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); x*w = x_hi w_hi + x_lo w_hi + x_hi w_lo + O(2^-16 |x w|)
+ * is ONE bfloat16 product over a three times longer K when the operands are concatenated along K (float32 accumulate):
+ * the reference's float32 Linear / conv arithmetic (HTR_VT.py:22-37,76; resnet18.py:26-31,59-63) on the bf16 matrix
+ * cores at a third of their rate instead of 1/16 (the f32-input MFMA), inside BASELINE.json's 1e-3 logit gate.
+ * src float32 [rows][cols] (row stride ld_src) ->
+ *   cat (may be NULL unless cat_f32 / transpose): [rows][3*cols], order 0 = (hi | lo | hi) -- the activation side,
+ *       order 1 = (hi | hi | lo) -- the weight side; bfloat16, or float32 holding the same bf16-exact values when cat_f32
+ *       (input of htrvt_pack_conv_weight); transpose: [cols][3*rows], block j of row c = part j of src[:, c]
+ *   hi, lo (may be NULL): bfloat16 [rows][cols] planes (weight gradients contract over rows: three accumulating launches) */
+int htrvt_split_bf16(const float* src, int64_t rows, int cols, int64_t ld_src, void* cat, int order, int cat_f32, int transpose,
+                     void* hi, void* lo, void* stream);
 
 /* ---- optimizer step (train.py:94 AdamW(betas .9/.99, wd .5) as one flat launch) -- */
 /* Statement order and rounding points of torch.optim.AdamW's single-tensor step; the hyper-parameters are doubles as in

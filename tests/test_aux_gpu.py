@@ -162,3 +162,33 @@ def test_pool_tokens_and_its_backward_match_max_pool2d(H, W, D, dtype):
     check(lib.htrvt_pool_tokens_bwd(ptr(dtok_d), ptr(x_d), ptr(keep_d), ptr(dx), B, H, N, D, dt(dtype), stream()),
           "pool_tokens_bwd")
     assert torch.equal(dx.float().cpu(), dx_ref)
+
+
+@pytest.mark.parametrize("rows,cols", [(4096, 768), (1000, 200), (37, 1728), (3, 9)])
+def test_split_bf16_forms(rows, cols):
+    """htrvt_split_bf16 (csrc/split.hip): hi = bf16(x), lo = bf16(x - hi), the concatenated forms in both orders, the
+    transposed form, the float32 copy of the parts, the planes -- exact against torch's own bfloat16 rounding; and
+    hi + lo within 2^-16 |x| of x (what the split-bf16 parity path relies on)"""
+    from htrvt_amd._lib import check, lib
+    from htrvt_amd.ops import ptr, stream
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * torch.logspace(-3, 3, cols)).cuda()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert ((hi.float() + lo.float()) - x).abs().max() <= 2.0 ** -16 * x.abs().max()
+    BF = torch.bfloat16
+    for order, parts in ((0, (hi, lo, hi)), (1, (hi, hi, lo))):
+        want = torch.cat(parts, dim=1)
+        cat = torch.empty(rows, 3 * cols, dtype=BF, device="cuda")
+        check(lib.htrvt_split_bf16(ptr(x), rows, cols, cols, ptr(cat), order, 0, 0, None, None, stream()))
+        assert torch.equal(cat, want)
+        catf = torch.empty(rows, 3 * cols, dtype=torch.float32, device="cuda")
+        check(lib.htrvt_split_bf16(ptr(x), rows, cols, cols, ptr(catf), order, 1, 0, None, None, stream()))
+        assert torch.equal(catf, want.float())
+        catt = torch.empty(cols, 3 * rows, dtype=BF, device="cuda")
+        check(lib.htrvt_split_bf16(ptr(x), rows, cols, cols, ptr(catt), order, 0, 1, None, None, stream()))
+        assert torch.equal(catt, torch.cat([p.t() for p in parts], dim=1))
+    if cols % 8 == 0:
+        h2, l2 = torch.empty(rows, cols, dtype=BF, device="cuda"), torch.empty(rows, cols, dtype=BF, device="cuda")
+        check(lib.htrvt_split_bf16(ptr(x), rows, cols, cols, None, 0, 0, 0, ptr(h2), ptr(l2), stream()))
+        assert torch.equal(h2, hi) and torch.equal(l2, lo)

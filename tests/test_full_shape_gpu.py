@@ -1,13 +1,18 @@
 """Parity at the HEADLINE shape: HTR-VT base (d768 / 4L / 6h, nb_cls 80), 64x1024 lines, batch 128 -- BASELINE.json
 configs 2 / 3, the shape bench.py measures.  Kernel variants are picked per shape (gemm_dma.hip pick_bn /
-use_loader_waves, engine._split_k incl. the XCD-grouped multiples of 8, parity-class dgrad launches), so this is the
-only place the bench's hot variants meet the oracle end to end.
+use_loader_waves, the persistent 8-phase walk, engine._split_k incl. the XCD-grouped multiples of 8, parity-class dgrad
+launches), so this is the only place the bench's hot variants meet the oracle end to end.
 
-  * float32 eval logits vs the oracle: eval-mode BatchNorm makes samples independent, so an 8-image subset of the
-    batch through the CPU oracle pins the whole batch's kernels (every launch still runs at B = 128): <= 1e-3;
-  * float32 train-mode (batch statistics over all 128 images, span mask on) logits and CTC loss vs the oracle run on
-    the full batch (forward only, ~20-40 s of host time): <= 1e-3 on the logits, 1e-5 relative on the loss;
-  * bfloat16 (the measured path): reported against the same oracle outputs and gated loosely."""
+  * float32 path AND split-bf16 parity path (float32 activations, hi + lo bf16 operands on the bf16 matrix cores):
+    eval logits vs the oracle on an 8-image subset (eval-mode BatchNorm makes samples independent; every launch still
+    runs at B = 128), train-mode logits (batch statistics over all 128 images, span mask on) and CTC loss vs the oracle's
+    full-batch forward: <= 1e-3 on the logits (BASELINE.json north_star), 1e-5 relative on the loss;
+  * bfloat16 (the measured path): gated against what the REFERENCE ARITHMETIC ITSELF loses in bfloat16 -- the oracle
+    under torch.autocast(bfloat16) -- in relative L2 norm, eval and train (profiles/r04_bf16_ladder.md: the train-mode
+    error enters through the 16 batch-statistics BatchNorms, in the reference exactly as here);
+  * one full fwd + CTC + bwd of all three paths, gradient by gradient against torch autograd over the oracle on the full
+    batch (needs ~45 GB of host memory: skipped on smaller hosts)."""
+import os
 from functools import partial
 
 import numpy as np
@@ -20,11 +25,23 @@ from oracle import htrvt_oracle as O
 pytestmark = pytest.mark.gpu
 
 B, W, NB_CLS = 128, 1024, 80
+SPLIT = "split_bf16"
+
+
+def _host_gib():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
 
 
 @pytest.fixture(scope="module")
 def setup():
-    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
     cfg = O.Config(NB_CLS, (64, W), embed_dim=768, depth=4, num_heads=6)
     sd = O.init_state_dict(cfg, seed=123, randomize_affine=True)
     x, targets, lengths = O.synthetic_batch(B, 64, W, NB_CLS, cfg.num_patches, seed=0)
@@ -34,11 +51,15 @@ def setup():
         sub = torch.arange(0, B, 16)                                   # 8 images spread over the batch
         ref_eval = O.forward(sd, cfg, x[sub], train=False)
         ref_train = O.forward(sd, cfg, x, keep_mask=keep, train=True)
+        # the reference arithmetic with bfloat16 operands: what bf16 costs the reference itself
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ac_eval = O.forward(sd, cfg, x[sub], train=False).float()
+            ac_train = O.forward(sd, cfg, x, keep_mask=keep, train=True).float()
     lp = ref_train.double().permute(1, 0, 2).log_softmax(2)             # compute_loss (train.py:21-30) in float64
     ref_nll = torch.nn.functional.ctc_loss(lp, torch.from_numpy(targets), torch.full((B,), lp.shape[0], dtype=torch.int32),
                                            torch.from_numpy(lengths), blank=0, reduction="none", zero_infinity=True).numpy()
     return dict(cfg=cfg, sd=sd, x=x, targets=targets, lengths=lengths, keep=keep, sub=sub, ref_eval=ref_eval,
-                ref_train=ref_train, ref_nll=np.asarray(ref_nll))
+                ref_train=ref_train, ref_nll=np.asarray(ref_nll), ac_eval=ac_eval, ac_train=ac_train)
 
 
 def _model(cfg, sd, dtype):
@@ -50,7 +71,11 @@ def _model(cfg, sd, dtype):
     return m.cuda()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, SPLIT, torch.bfloat16])
 def test_headline_shape_eval_and_train_forward(setup, dtype):
     from htrvt_amd.ctc import ctc_forward_backward
     s = setup
@@ -59,31 +84,42 @@ def test_headline_shape_eval_and_train_forward(setup, dtype):
     m.eval()
     with torch.no_grad():
         y = m(xd)
-    err_eval = (y[s["sub"].cuda()].cpu() - s["ref_eval"]).abs().max().item()
+    y_eval = y[s["sub"].cuda()].cpu()
+    err_eval = (y_eval - s["ref_eval"]).abs().max().item()
     m.train()
     with torch.no_grad():
         yt = m(xd, keep_mask=s["keep"])
         nll, _ = ctc_forward_backward(yt, s["targets"], s["lengths"], want_grad=False)
-    err_train = (yt.cpu() - s["ref_train"]).abs().max().item()
+    yt = yt.cpu()
+    err_train = (yt - s["ref_train"]).abs().max().item()
     rel_loss = abs(float(nll.mean()) - float(s["ref_nll"].mean())) / abs(float(s["ref_nll"].mean()))
-    agree = (yt.cpu().argmax(-1) == s["ref_train"].argmax(-1)).float().mean().item()
-    print(f"{dtype} B=128 64x1024 d768: eval logits max-abs {err_eval:.3e}, train logits max-abs {err_train:.3e}, "
-          f"CTC loss rel {rel_loss:.3e}, arg-max agreement {agree:.4f}")
-    if dtype == torch.float32:
+    agree = (yt.argmax(-1) == s["ref_train"].argmax(-1)).float().mean().item()
+    l2_eval, l2_train = _rel_l2(y_eval, s["ref_eval"]), _rel_l2(yt, s["ref_train"])
+    print(f"{dtype} B=128 64x1024 d768: eval logits max-abs {err_eval:.3e} rel-L2 {l2_eval:.3e}, train logits max-abs {err_train:.3e} "
+          f"rel-L2 {l2_train:.3e}, CTC loss rel {rel_loss:.3e}, arg-max agreement {agree:.4f}")
+    if dtype != torch.bfloat16:
         assert err_eval < 1e-3 and err_train < 1e-3
         assert rel_loss < 1e-5
     else:
-        assert err_eval < 0.25 and err_train < 0.25 and agree > 0.95 and rel_loss < 2e-2
+        ac_eval, ac_train = _rel_l2(s["ac_eval"], s["ref_eval"]), _rel_l2(s["ac_train"], s["ref_train"])
+        ac_agree = (s["ac_train"].argmax(-1) == s["ref_train"].argmax(-1)).float().mean().item()
+        print(f"   the oracle under bf16 autocast: eval rel-L2 {ac_eval:.3e}, train rel-L2 {ac_train:.3e} (max-abs "
+              f"{(s['ac_train'] - s['ref_train']).abs().max().item():.3e}), arg-max agreement {ac_agree:.4f}")
+        assert l2_eval < 1.25 * ac_eval and l2_train < 1.25 * ac_train, (l2_eval, ac_eval, l2_train, ac_train)
+        assert agree > ac_agree - 0.01 and rel_loss < 2e-2
+        assert err_eval < 6e-2 and err_train < 0.3
 
 
-def test_headline_shape_training_step_bf16_vs_f32_gradients(setup):
-    """one fwd + CTC + bwd at the bench shape on both paths: the bf16 step's gradients against the float32 parity path's
-    (which the smaller-shape tests pin to the oracle), every tensor by cosine; exercises split-K 8 / 72 wgrad, the fused
-    dgrad epilogues, the fused attention backward and the parity-class launches at exactly the bench's shapes"""
+def test_headline_shape_training_step_gradients(setup):
+    """one fwd + CTC + bwd at the bench shape on all three paths: every gradient tensor against torch autograd over the CPU
+    restatement on the FULL batch of 128 (float32, ~1-2 minutes and ~45 GB of host memory).  float32 and split-bf16 must sit
+    at rounding level (ReLU / arg-max flips of a few elements bound the L2 error of the stem tensors, see smoke()); bf16 by
+    cosine.  Exercises split-K 8 / 72 wgrad, the fused dgrad epilogues, the fused attention backward, the parity-class
+    launches and the persistent Linear kernels at exactly the bench's shapes."""
     import htrvt_amd
     s = setup
     grads = {}
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, SPLIT, torch.bfloat16):
         m = _model(s["cfg"], s["sd"], dtype).train()
         y = m(s["x"].cuda(), keep_mask=s["keep"])
         loss = htrvt_amd.ctc_loss(y, s["targets"], s["lengths"])
@@ -92,8 +128,10 @@ def test_headline_shape_training_step_bf16_vs_f32_gradients(setup):
         del m, y, loss
         torch.cuda.empty_cache()
     g32, l32 = grads[torch.float32]
+    gsp, lsp = grads[SPLIT]
     g16, l16 = grads[torch.bfloat16]
-    assert abs(l32 - float(s["ref_nll"].mean())) < 1e-5 * abs(l32)
+    ref_loss = float(s["ref_nll"].mean())
+    assert abs(l32 - ref_loss) < 1e-5 * abs(l32) and abs(lsp - ref_loss) < 1e-5 * abs(lsp)
     assert abs(l16 - l32) < 2e-2 * abs(l32)
     worst = (1.0, None)
     for n in g32:
@@ -103,30 +141,37 @@ def test_headline_shape_training_step_bf16_vs_f32_gradients(setup):
         cos = float(a @ b_ / (a.norm() * b_.norm() + 1e-30))
         worst = min(worst, (cos, n))
         assert cos > 0.9, (n, cos)
+        e = float((gsp[n].flatten().double() - b_).norm() / (b_.norm() + 1e-30))
+        assert e < 2e-2, ("split vs float32", n, e)
     print("B=128 64x1024 bf16 vs f32 training-step gradients: worst cosine", worst)
 
-    # ---- and both against the ORACLE's backward at this shape: torch autograd over the CPU restatement on the full batch of
-    # 128 (float32, ~1-2 minutes of host time, ~40 GB of host memory).  Per tensor: relative L2 error and cosine; the
-    # float32 path must sit at rounding level (ReLU / arg-max flips of a few elements bound the L2 error, see smoke()).
+    if _host_gib() < 60:
+        pytest.skip(f"oracle backward on the full batch needs ~45 GB of host memory ({_host_gib():.0f} GiB available)")
     import time
     t0 = time.time()
     loss_ref, _, gref, _ = O.loss_and_grads(s["sd"], s["cfg"], s["x"], s["targets"], s["lengths"], keep_mask=s["keep"], train=True)
-    print(f"oracle fwd+bwd on the full batch: {time.time() - t0:.0f} s, loss {loss_ref:.6f} (GPU float32 {l32:.6f})")
-    assert abs(l32 - loss_ref) < 1e-5 * abs(loss_ref)
-    worst32, worst16 = (0.0, None), (1.0, None)
+    print(f"oracle fwd+bwd on the full batch: {time.time() - t0:.0f} s, loss {loss_ref:.6f} (GPU float32 {l32:.6f}, split-bf16 {lsp:.6f})")
+    assert abs(l32 - loss_ref) < 1e-5 * abs(loss_ref) and abs(lsp - loss_ref) < 1e-5 * abs(loss_ref)
+    worst32, worstsp, worst16 = (0.0, None), (0.0, None), (1.0, None)
     for n, r in gref.items():
         if n not in g32 or r.numel() < 64 or n.endswith("attn.qkv.bias"):
             continue
         r = r.flatten().double()
-        a32, a16 = g32[n].flatten().double(), g16[n].flatten().double()
+        a32, asp, a16 = g32[n].flatten().double(), gsp[n].flatten().double(), g16[n].flatten().double()
         e32 = float((a32 - r).norm() / (r.norm() + 1e-30))
+        esp = float((asp - r).norm() / (r.norm() + 1e-30))
         c16 = float(a16 @ r / (a16.norm() * r.norm() + 1e-30))
-        worst32, worst16 = max(worst32, (e32, n)), min(worst16, (c16, n))
-        assert e32 < 2e-2, (n, e32)
+        worst32, worstsp, worst16 = max(worst32, (e32, n)), max(worstsp, (esp, n)), min(worst16, (c16, n))
+        # per-tensor bounds: the encoder / head see no ReLU or arg-max discontinuity (measured 3e-5), the stem does (<= 5e-3)
+        tol = 1e-3 if n.startswith(("blocks.", "head.", "norm.")) else 1.5e-2
+        assert e32 < tol, (n, e32)
+        assert esp < tol, (n, esp)
         assert c16 > 0.9, (n, c16)
     for n in ("head.weight", "blocks.3.mlp.fc1.weight", "blocks.0.attn.qkv.weight", "patch_embed.layer3.1.conv2.weight",
               "patch_embed.layer1.0.conv1.weight", "patch_embed.conv1.weight"):
         r = gref[n].flatten().double()
         print(f"   {n:40s} float32 rel-L2 {float((g32[n].flatten().double() - r).norm() / r.norm()):.3e}   "
+              f"split-bf16 rel-L2 {float((gsp[n].flatten().double() - r).norm() / r.norm()):.3e}   "
               f"bf16 cosine {float(g16[n].flatten().double() @ r / (g16[n].flatten().double().norm() * r.norm())):.5f}")
-    print("B=128 64x1024 gradients vs the oracle: float32 worst rel-L2", worst32, "| bf16 worst cosine", worst16)
+    print("B=128 64x1024 gradients vs the oracle: float32 worst rel-L2", worst32, "| split-bf16 worst rel-L2", worstsp,
+          "| bf16 worst cosine", worst16)

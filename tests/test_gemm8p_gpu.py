@@ -360,3 +360,87 @@ def test_halo_conv_wgrad_exact(cfg, slabs):
         if tile == 13:
             assert "gemm_hwgrad_kernel" in _last_kernel(), _last_kernel()
         assert torch.equal(dwp.double().cpu(), base + want), (tile, float((dwp.double().cpu() - base - want).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Persistent form (csrc/gemm8pp_impl.h): one workgroup per CU walks its tiles, the epilogue of a tile is folded into the
+# first k-tile of the next.  Shapes with MORE tiles than CUs (several tiles per workgroup: the folded flush), exactly as
+# many (every tile is a workgroup's last: the trailing flush), row / column tails, both tile widths, padded leading dims.
+# ---------------------------------------------------------------------------------------------------------------------
+def _ncu():
+    return torch.cuda.get_device_properties(0).multi_processor_count & ~7
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(8192, 4608, 384, 14),     # 32 x 18 tiles of 256 x 256
+                                        (4096, 4096, 256, 14),     # 16 x 16 = 256 tiles: one per CU
+                                        (8000, 2312, 512, 14),     # row tail (8000 = 31.25 tiles), column tail
+                                        (16384, 768, 768, 15),     # 64 x 4 tiles of 256 x 192 (the proj / fc2 width)
+                                        (10000, 1536, 256, 15),
+                                        (8192, 4608, 384, 15)])
+def test_persistent_plain_exact(M, N, K, tile):
+    ops = T._ops()
+    A, B = T._ints((M, K), seed=11), T._ints((N, K), seed=12)
+    bias = T._ints((N,), lo=-20, hi=21, seed=13)
+    ref = (A @ B.t() + bias).to(BF).double()
+    a, b = A.to(BF).cuda(), B.to(BF).cuda()
+    for with_bias in (True, False):
+        c = torch.full((M, N + 8), 7.0, dtype=BF, device="cuda")
+        ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, bias=bias.float().cuda() if with_bias else None, tile=tile)
+        k = _last_kernel()
+        assert "gemm8pp_kernel" in k and f"Cfg<{256 if tile == 14 else 192}" in k, k
+        got = c.double().cpu()
+        want = ref if with_bias else (A @ B.t()).to(BF).double()
+        assert torch.equal(got[:, :N], want), (with_bias, int((got[:, :N] != want).sum()))
+        assert (got[:, N:] == 7.0).all()
+    # the auto route (its own choice of kernel and width; the model's shapes are pinned in test_persistent_repeated_launches...)
+    c = torch.empty((M, N), dtype=BF, device="cuda")
+    ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.float().cuda())
+    assert torch.equal(c.double().cpu(), ref), _last_kernel()
+
+
+@pytest.mark.parametrize("M,N,K,tiles", [(8192, 3072, 768, (14, 10)), (16384, 768, 256, (15, 11)), (8192, 3072, 768, (15, 11))])
+def test_persistent_gelu_epilogue(M, N, K, tiles):
+    """bias + exact-erf GELU + saved pre-activation (fc1 forward) through the folded flush: bit-identical to the
+    one-tile-per-workgroup kernel (same arithmetic, same rounding points), and both against float64"""
+    ops = T._ops()
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    a, b = A.to(BF).cuda(), B.to(BF).cuda()
+    outs = {}
+    for tile in tiles:
+        c = torch.empty(M, N, dtype=BF, device="cuda")
+        pr = torch.empty(M, N, dtype=BF, device="cuda")
+        ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1, bias=bias.cuda(), preact=pr, tile=tile)
+        assert ("gemm8pp_kernel" if tile >= 13 else "gemm8p_kernel<") in _last_kernel(), _last_kernel()
+        outs[tile] = (c, pr)
+    assert torch.equal(outs[tiles[0]][0], outs[tiles[1]][0]) and torch.equal(outs[tiles[0]][1], outs[tiles[1]][1])
+    pre = (a.double() @ b.double().t()) * 0.5 + bias.double().cuda()
+    pq = outs[tiles[0]][1].double()
+    assert (pq - pre).abs().max() <= 2.0 ** -8 * pre.abs().max()
+    assert (outs[tiles[0]][0].double() - F.gelu(pq)).abs().max() <= 2.0 ** -8 * pq.abs().max() + 2e-6
+    # without a saved pre-activation
+    c2 = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(a, b, c2, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1, bias=bias.cuda(), tile=tiles[0])
+    assert "gemm8pp_kernel" in _last_kernel()
+    assert torch.equal(c2, outs[tiles[0]][0])
+
+
+def test_persistent_repeated_launches_are_bit_identical():
+    """race screen: the folded flush reads accumulators the next phase overwrites and a bias slot the next tile's DMA
+    refills; 20 launches of the model's qkv shape on random data must agree bit for bit with the first and with the
+    one-tile-per-workgroup kernel"""
+    ops = T._ops()
+    M, N, K = 32768, 2304, 768
+    g = torch.Generator().manual_seed(9)
+    a = (torch.randn(M, K, generator=g)).to(BF).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.05).to(BF).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(a, b, ref, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, tile=9)
+    assert "gemm8p_kernel<" in _last_kernel()
+    for it in range(20):
+        c = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+        assert "gemm8pp_kernel" in _last_kernel()
+        assert torch.equal(c, ref), (it, int((c != ref).sum()))

@@ -546,10 +546,18 @@ static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int z
     int r = gemm8p_try_launch(d, q, zdim, st);   // 8-phase schedule, epilogue from the accumulators (gemm8p.hip)
     if (r != 0) return r < 0 ? r : 0;
     q = p;
+    r = gemm8pt_try_launch(d, q, zdim, st);      // the same schedule for MN-major operands: Linear weight gradients
+    if (r != 0) return r < 0 ? r : 0;
+    q = p;
     r = gemm_dma_try_launch(d, q, zdim, st);     // one barrier per k-tile, LDS-staged epilogue (gemm_dma.hip)
     if (r != 0) return r < 0 ? r : 0;
   }
   HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");
+  // per-tile column sums: the caller sized `colstats` with htrvt_gemm_num_mtiles, i.e. for the 256-row tiles of the LDS-DMA
+  // family; when that family declines the launch (an operand of 2 GiB or more) the 128-row tiles below would write twice as
+  // many rows -- refuse instead of overrunning the buffer (the engine splits such a launch along the batch)
+  HTRVT_REQUIRE(!(d->colstats != nullptr && d->dtype == HTRVT_BF16 && d->tile != 1 && gemm_dma_num_mtiles(d) > 0),
+                "htrvt_gemm: column sums of a bfloat16 launch need the LDS-DMA kernels (operands below 2 GiB): split the batch");
   HTRVT_REQUIRE(!fused_bwd, "htrvt_gemm: relu_src / bnb_* need the bfloat16 LDS-DMA kernel with loader waves");
   if (d->dtype == HTRVT_BF16) {
     if (bn == 64) return dispatch_layout<bf16_t, 128, 64>(d, p, zdim, st);

@@ -9,6 +9,7 @@ using namespace htrvt;
 namespace htrvt {
 int gemm8p_dispatch_plain(int bn, int epi, const KParams&, int, hipStream_t);
 int gemm8pp_dispatch_plain(int bn, int epi, const KParams&, int nwg, hipStream_t);
+int gemm8pt_dispatch(const KParams&, int zdim, hipStream_t);
 int gemm8p_dispatch_conv(int bn, int gather, int epi, const KParams&, int, hipStream_t);
 }  // namespace htrvt
 
@@ -81,6 +82,29 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   if (d->colstats != nullptr && d->gather != HTRVT_GATHER_CONV_FWD) return false;
   if (d->act != 1 && d->act != 2 && d->preact != nullptr) return false;   // pre-activation without GELU: not built
   return true;
+}
+
+// MN-major x MN-major plain products with float32 output -- the Linear weight gradients dW = dy^T x -- on the 8-phase
+// schedule with transposed fragment reads (gemm8pt_impl.h).  tile 0 (auto) and 16; 3 / 4 / 6 keep naming the older kernels.
+bool gemm8pt_serves(const HtrvtGemmDesc* d) {
+  if (d->tile != 0 && d->tile != 16) return false;
+  if (d->dtype != HTRVT_BF16 || d->gather != HTRVT_GATHER_NONE || d->a_layout != HTRVT_MNMAJOR || d->b_layout != HTRVT_MNMAJOR) return false;
+  if (!d->c_f32 || d->batch > 1 || d->M < 256 || d->N < 256 || d->K < 256) return false;
+  if ((d->M & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return false;
+  if ((reinterpret_cast<unsigned long long>(d->A) & 15) || (reinterpret_cast<unsigned long long>(d->B) & 15) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return false;
+  if (d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr || d->colscale != nullptr) return false;
+  const long long lim = (1ll << 31) - 64;
+  if ((long long)d->K * d->lda * 2 >= lim || (long long)d->K * d->ldb * 2 >= lim) return false;
+  return true;
+}
+
+int gemm8pt_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
+  if (!gemm8pt_serves(d)) return 0;
+  // plain stores only: the whole K in one launch without accumulation, or K ranges into slabs (summed by splitk_reduce_kernel)
+  if (p.split_k > 1 ? p.slab_stride == 0 : p.accumulate != 0) return 0;
+  p.tiles_m = (d->M + 255) / 256;
+  p.tiles_n = (d->N + 255) / 256;
+  return gemm8pt_dispatch(p, zdim, st);
 }
 
 // returns 1 if it launched, 0 if this family has no kernel for the call, < 0 on error

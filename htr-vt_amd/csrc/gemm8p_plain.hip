@@ -2,6 +2,7 @@
 // saved pre-activation, residual) and dgrad against the transposed weight copy (plain, * GELU').  Own translation unit
 // (the Makefile builds the units in parallel).
 #include "gemm8pp_impl.h"
+#include "gemm8pt_impl.h"
 
 namespace htrvt {
 
@@ -29,6 +30,9 @@ int gemm8pp_dispatch_plain(int bn, int epi, const KParams& p, int nwg, hipStream
   }
   return 0;
 }
+
+// MN-major x MN-major operands, float32 output (gemm8pt_impl.h): the Linear weight gradients
+int gemm8pt_dispatch(const KParams& p, int zdim, hipStream_t st) { return g8::launch_t(p, zdim, st); }
 
 int gemm8p_dispatch_plain(int bn, int epi, const KParams& p, int zdim, hipStream_t st) {
   if (bn == 256) return by_epi<g8::Cfg<256, 2, 4>>(epi, p, zdim, st);

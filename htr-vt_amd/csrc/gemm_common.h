@@ -243,5 +243,7 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
 int gemm_dma_num_mtiles(const HtrvtGemmDesc* d);
 // defined in gemm8p.hip (8-phase kernels, 256-row tiles): same return convention
 int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st);
+int gemm8pt_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st);   // MN-major x MN-major, float32 C
+bool gemm8pt_serves(const HtrvtGemmDesc* d);
 
 }  // namespace htrvt

@@ -96,7 +96,42 @@ __global__ __launch_bounds__(NT_) void split_any_kernel(const float* __restrict_
   }
 }
 
+// dx [B][Hi][Wi][C] = the parity-class results of a strided conv dgrad, each a dense [B][Hq][Wq][C] float32 matrix
+// (class (a, b) holds the pixels hi % sh == a, wi % sw == b), + residual
+__global__ __launch_bounds__(NT_) void class_scatter_kernel(const float* __restrict__ c00, const float* __restrict__ c01,
+                                                            const float* __restrict__ c10, const float* __restrict__ c11,
+                                                            const float* __restrict__ residual, float* __restrict__ dx, int B,
+                                                            int Hi, int Wi, int C4, int sh, int sw) {
+  const long long total = (long long)B * Hi * Wi * C4;
+  for (long long t = (long long)blockIdx.x * NT_ + threadIdx.x; t < total; t += (long long)gridDim.x * NT_) {
+    const int c = (int)(t % C4);
+    long long pix = t / C4;
+    const int wi = (int)(pix % Wi);
+    pix /= Wi;
+    const int hi = (int)(pix % Hi);
+    const int b = (int)(pix / Hi);
+    const int a = hi % sh, bc = wi % sw;
+    const int Hq = (Hi - a + sh - 1) / sh, Wq = (Wi - bc + sw - 1) / sw;
+    const float* src = a == 0 ? (bc == 0 ? c00 : c01) : (bc == 0 ? c10 : c11);
+    f32x4_t v = reinterpret_cast<const f32x4_t*>(src)[(((long long)b * Hq + hi / sh) * Wq + wi / sw) * C4 + c];
+    if (residual != nullptr) v += reinterpret_cast<const f32x4_t*>(residual)[t];
+    reinterpret_cast<f32x4_t*>(dx)[t] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int htrvt_class_scatter_f32(const float* c00, const float* c01, const float* c10, const float* c11, const float* residual,
+                                       float* dx, int B, int Hi, int Wi, int C, int sh, int sw, void* stream) {
+  HTRVT_REQUIRE(dx != nullptr && c00 != nullptr && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0, "htrvt_class_scatter_f32: bad shape");
+  HTRVT_REQUIRE((sh == 1 || sh == 2) && (sw == 1 || sw == 2) && (sh == 1 || c10 != nullptr) && (sw == 1 || c01 != nullptr) &&
+                    (sh == 1 || sw == 1 || c11 != nullptr), "htrvt_class_scatter_f32: one dense matrix per parity class");
+  const long long total = (long long)B * Hi * Wi * (C / 4);
+  const unsigned grid = (unsigned)((total + NT_ - 1) / NT_ > 65536 * 4 ? 65536 * 4 : (total + NT_ - 1) / NT_);
+  hipLaunchKernelGGL(class_scatter_kernel, dim3(grid), dim3(NT_), 0, (hipStream_t)stream, c00, c01, c10, c11, residual, dx, B, Hi, Wi,
+                     C / 4, sh, sw);
+  return check_launch("class_scatter_f32");
+}
 
 extern "C" int htrvt_split_bf16(const float* src, int64_t rows, int cols, int64_t ld_src, void* cat, int order, int cat_f32,
                                 int transpose, void* hi, void* lo, void* stream) {

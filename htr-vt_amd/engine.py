@@ -185,14 +185,28 @@ class Engine:
                                    ptr(hi), ptr(lo), stream()), "split_bf16")
         return c, hi, lo
 
+    @staticmethod
+    def _batch_slices(B, nbytes, rows_per_image):
+        """smallest number of equal batch slices that keeps an operand of `nbytes` below 2 GiB per launch (M tiles of 256
+        rows must not straddle slices: the per-tile column sums are concatenated)"""
+        n = 1
+        while n < B and (B % n or nbytes // n >= 2 ** 31 - 4096 or (n > 1 and (B // n * rows_per_image) % 256)):
+            n += 1
+        return n
+
     def _split_act(self, t, cols, cat=True, planes=False):
         """split of an activation / gradient tensor whose innermost extent is `cols`, remembered while the backward may ask
         for it again (the same gradient is the A operand of a dgrad launch and the B operand of three wgrad launches)"""
+        cur = torch.cuda.current_stream()
         for ent in self._split_cache:
             if ent[0] is t and (ent[1] is not None or not cat) and (ent[2] is not None or not planes):
+                if ent[4] != cur:      # made on the main stream, read by a weight-gradient launch on the side stream: the
+                    for u in ent[1:4]:  # caching allocator must not hand the block out again before that launch has run
+                        if u is not None:
+                            u.record_stream(cur)
                 return ent[1], ent[2], ent[3]
         c, hi, lo = self._split(t, t.numel() // cols, cols, order=0, cat=cat, planes=planes)
-        self._split_cache = [e for e in self._split_cache if e[0] is not t][-2:] + [(t, c, hi, lo)]
+        self._split_cache = [e for e in self._split_cache if e[0] is not t][-2:] + [(t, c, hi, lo, cur)]
         return c, hi, lo
 
     def _lin_w_split(self, name, w):
@@ -425,7 +439,10 @@ class Engine:
         """dw[N,K] += dy^T x ; dbias[N] += colsum(dy)."""
         M, N = dy.shape
         K = x.shape[1]
-        sk = self._split_k(N, K, M)
+        tiling = None
+        if self.gdt == torch.bfloat16 and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0:
+            tiling = (((N + 255) // 256) * ((K + 255) // 256), 256, 256)     # the 8-phase MN-major kernel's tiles (csrc/gemm8pt_impl.h)
+        sk = self._split_k(N, K, M, tiling=tiling)
         if self.split and not plain:      # the contraction runs over the rows: hi / lo planes, three accumulating launches
             _, dyh, dyl = self._split_act(dy, N, cat=False, planes=True)
             _, xh, xl = self._split_act(x, K, cat=False, planes=True)
@@ -456,10 +473,24 @@ class Engine:
             kw = dict(colscale=bn[0], bias=bn[1], residual=residual, act=3 if relu else 0)
         if self.split:      # the same convolution over 3 Ci input channels: (hi | lo | hi) pixels against the (hi | hi | lo) pack
             x3, _, _ = self._split_act(x, g.Ci)
-            g3 = ConvGeom(g.B, g.Hi, g.Wi, 3 * g.Ci, g.Co, g.kh, (g.sh, g.sw), g.ph)
             cp3 = cpad(3 * g.Ci, self.gdt)
-            gemm(x3, wf, y, dtype=self.gdt, M=M, N=g.Co, K=g.taps * cp3, lda=3 * g.Ci, ldb=g.taps * cp3, ldc=g.Co,
-                 gather=GATHER_CONV_FWD, geom=g3, Cpad=cp3, colstats=cs, c_f32=True, **kw)
+            # the tripled operand of a layer-1 convolution passes 2 GiB at 128 images (the LDS-DMA kernels address operands
+            # through 2 GiB buffer descriptors): one launch per batch slice, each with its own rows of the column sums
+            n = self._batch_slices(g.B, x3.numel() * 2, g.Ho * g.Wo)
+            Bc = g.B // n
+            Mc = Bc * g.Ho * g.Wo
+            g3 = ConvGeom(Bc, g.Hi, g.Wi, 3 * g.Ci, g.Co, g.kh, (g.sh, g.sw), g.ph)
+            rows_c = ops.gemm_num_mtiles(Mc, g.Co, self.gdt, gather=GATHER_CONV_FWD) if want_stats else 0
+            if want_stats:
+                rows = n * rows_c
+                cs = self._empty(rows + 64, 2, g.Co, dtype=torch.float32)
+            for c in range(n):
+                kc = dict(kw)
+                if kc.get("residual") is not None:
+                    kc["residual"] = kc["residual"].view(-1)[c * Mc * g.Co:]
+                gemm(x3, wf, y, dtype=self.gdt, M=Mc, N=g.Co, K=g.taps * cp3, lda=3 * g.Ci, ldb=g.taps * cp3, ldc=g.Co,
+                     gather=GATHER_CONV_FWD, geom=g3, Cpad=cp3, colstats=cs[c * rows_c:] if want_stats else None, c_f32=True,
+                     a_off=c * Bc * g.Hi * g.Wi * 3 * g.Ci, c_off=c * Mc * g.Co, **kc)
             return y, cs, rows
         gemm(x, wf, y, dtype=self.dtype, M=M, N=g.Co, K=g.taps * cpi, lda=g.Ci, ldb=g.taps * cpi, ldc=g.Co,
              gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs, **kw)
@@ -473,7 +504,7 @@ class Engine:
         return ops.gemm_num_mtiles(g.B * g.Hi * g.Wi, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
 
     def _dgrad_by_class(self, g):
-        return self.dtype == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
+        return self.gdt == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
 
     def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None, relu_bn=None):
         """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only).
@@ -484,6 +515,32 @@ class Engine:
         assert extra is None or self._dgrad_by_class(g)
         assert relu_bn is None or (not self._dgrad_by_class(g) and relu_src is None and residual is None and bnb is not None and len(bnb) == 1)
         wtaps = g.taps + (1 if extra is not None else 0)       # taps per row of the packed weight
+        if self._dgrad_by_class(g) and self.split:
+            # split-bf16: the same parity-class launches over 3 Co gradient channels; each leaves a dense float32 [B,Hq,Wq,Ci]
+            # matrix (the float32 epilogue of the LDS-DMA kernels stores class rows as they come), one pass interleaves the
+            # classes into dx and adds the residual (htrvt_class_scatter_f32)
+            assert relu_src is None and bnb is None and relu_bn is None and extra is None
+            dy3, _, _ = self._split_act(dy, g.Co, cat=True, planes=True)
+            cp3 = cpad(3 * g.Co, self.gdt)
+            g3 = ConvGeom(g.B, g.Hi, g.Wi, g.Ci, 3 * g.Co, g.kh, (g.sh, g.sw), g.ph)
+            parts = {}
+            for a in range(g.sh):
+                for b in range(g.sw):
+                    nt = sum(1 for dy_ in range(g.kh) if (a + g.ph - dy_) % g.sh == 0) * \
+                         sum(1 for dx_ in range(g.kw) if (b + g.pw - dx_) % g.sw == 0)
+                    Hq, Wq = (g.Hi - a + g.sh - 1) // g.sh, (g.Wi - b + g.sw - 1) // g.sw
+                    if nt == 0:      # no tap reaches this class (1x1 strided conv): its gradient is zero
+                        parts[(a, b)] = torch.zeros(g.B, Hq, Wq, g.Ci, dtype=torch.float32, device=self.dev)
+                        continue
+                    part = self._empty(g.B, Hq, Wq, g.Ci)
+                    # cls selects the taps and the gathered pixels; with cls the float32 epilogue writes row m of the class
+                    # at row m of C: a dense matrix
+                    gemm(dy3, wd, part, dtype=self.gdt, M=g.B * Hq * Wq, N=g.Ci, K=nt * cp3, lda=3 * g.Co, ldb=g.taps * cp3, ldc=g.Ci,
+                         gather=GATHER_CONV_DGRAD, geom=g3, Cpad=cp3, cls=(a, b), c_f32=True)
+                    parts[(a, b)] = part
+            check(lib.htrvt_class_scatter_f32(ptr(parts[(0, 0)]), ptr(parts.get((0, 1))), ptr(parts.get((1, 0))), ptr(parts.get((1, 1))),
+                                              ptr(residual), ptr(dx), g.B, g.Hi, g.Wi, g.Ci, g.sh, g.sw, stream()), "class_scatter_f32")
+            return dx
         if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it
             tile0 = 0
@@ -514,10 +571,16 @@ class Engine:
         if self.split:      # 3 Co gradient channels: (hi | lo | hi) against the (hi | hi | lo) dgrad pack
             assert relu_src is None and bnb is None and relu_bn is None
             dy3, _, _ = self._split_act(dy, g.Co, cat=True, planes=True)
-            g3 = ConvGeom(g.B, g.Hi, g.Wi, g.Ci, 3 * g.Co, g.kh, (g.sh, g.sw), g.ph)
             cp3 = cpad(3 * g.Co, self.gdt)
-            gemm(dy3, wd, dx, dtype=self.gdt, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cp3, lda=3 * g.Co, ldb=g.taps * cp3,
-                 ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g3, Cpad=cp3, residual=residual, c_f32=True)
+            n = self._batch_slices(g.B, dy3.numel() * 2, g.Hi * g.Wi)
+            Bc = g.B // n
+            Mc = Bc * g.Hi * g.Wi
+            g3 = ConvGeom(Bc, g.Hi, g.Wi, g.Ci, 3 * g.Co, g.kh, (g.sh, g.sw), g.ph)
+            for c in range(n):
+                gemm(dy3, wd, dx, dtype=self.gdt, M=Mc, N=g.Ci, K=g.taps * cp3, lda=3 * g.Co, ldb=g.taps * cp3,
+                     ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g3, Cpad=cp3,
+                     residual=None if residual is None else residual.view(-1)[c * Mc * g.Ci:], c_f32=True,
+                     a_off=c * Bc * g.Ho * g.Wo * 3 * g.Co, c_off=c * Mc * g.Ci)
             return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
              ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb, relu_bn=relu_bn)
@@ -1049,7 +1112,7 @@ class Engine:
                 parts_d = parts[1] if len(parts) > 1 else None
             # downsample gradient as one more tap of the strided conv's class-(0,0) dgrad: d(conv1 out) and d(downsample
             # out) then live back to back in one allocation (the second gather source sits at a fixed offset from the first)
-            fuse_ds = (self.fuse_downsample_dgrad and blk["gd"] is not None and self._dgrad_by_class(blk["g1"]) and
+            fuse_ds = (self.fuse_downsample_dgrad and not self.split and blk["gd"] is not None and self._dgrad_by_class(blk["g1"]) and
                        2 * blk["ca"].numel() * blk["ca"].element_size() < 2 ** 31 - 64)     # A2 lies behind A inside ONE 2 GiB descriptor
             pair = self._empty(2, *blk["ca"].shape) if fuse_ds else None
             dca_out = pair[0] if fuse_ds else None

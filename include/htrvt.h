@@ -320,6 +320,11 @@ int htrvt_cast_transpose_f32(const float* src, void* dst, void* dst_t, int rows,
  *   hi, lo (may be NULL): bfloat16 [rows][cols] planes (weight gradients contract over rows: three accumulating launches) */
 int htrvt_split_bf16(const float* src, int64_t rows, int cols, int64_t ld_src, void* cat, int order, int cat_f32, int transpose,
                      void* hi, void* lo, void* stream);
+/* Split-bf16 strided conv dgrad (resnet18.py:26,59-63 backward): the parity-class launches of htrvt_gemm with float32 output
+ * leave one dense [B][Hq][Wq][C] matrix per class (a, b) = (hi % sh, wi % sw); this interleaves them into the NHWC gradient
+ * dx [B][Hi][Wi][C] (+ residual, may be NULL).  c01 / c10 / c11 may be NULL where the stride in that direction is 1. */
+int htrvt_class_scatter_f32(const float* c00, const float* c01, const float* c10, const float* c11, const float* residual, float* dx,
+                            int B, int Hi, int Wi, int C, int sh, int sw, void* stream);
 
 /* ---- optimizer step (train.py:94 AdamW(betas .9/.99, wd .5) as one flat launch) -- */
 /* Statement order and rounding points of torch.optim.AdamW's single-tensor step; the hyper-parameters are doubles as in

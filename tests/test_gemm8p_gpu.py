@@ -444,3 +444,55 @@ def test_persistent_repeated_launches_are_bit_identical():
         ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
         assert "gemm8pp_kernel" in _last_kernel()
         assert torch.equal(c, ref), (it, int((c != ref).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MN-major x MN-major operands on the 8-phase schedule (csrc/gemm8pt_impl.h): C = A^T B, float32, the Linear weight
+# gradients dW = dy^T x.  Exact integer data: row / column / K tails, padded leading dimensions, split-K into slabs.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,split,pad", [(768, 768, 4096, 1, 0), (3072, 768, 8192, 4, 0), (776, 264, 1000, 1, 8),
+                                             (2304, 768, 32768, 9, 0), (520, 1032, 2050, 3, 16), (256, 256, 256, 1, 0)])
+def test_mnmajor_8phase_exact(M, N, K, split, pad):
+    ops = T._ops()
+    A, B = T._ints((K, M + pad), lo=-2, hi=3, seed=21), T._ints((K, N + pad), lo=-2, hi=3, seed=22)
+    ref = A[:, :M].t() @ B[:, :N]
+    a, b = A.to(BF).cuda(), B.to(BF).cuda()
+    base = T._ints((M, N + 4), lo=-5, hi=6, seed=23).float().cuda()
+    for tile in (16, 3):       # this kernel, and the older one-barrier-per-k-tile kernel beside it
+        c = base.clone()
+        ws = torch.empty(split, M, N, dtype=torch.float32, device="cuda") if split > 1 else None
+        if split > 1:
+            ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=M + pad, ldb=N + pad, ldc=N + 4, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                     split_k=split, accumulate=True, c_f32=True, splitk_ws=ws, tile=tile)
+            want = base.double().cpu()
+            want[:, :N] += ref
+        else:
+            ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=M + pad, ldb=N + pad, ldc=N + 4, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                     c_f32=True, tile=tile)
+            want = base.double().cpu()
+            want[:, :N] = ref
+        k = _last_kernel()
+        assert ("gemm8pt_kernel" in k) == (tile == 16), k
+        assert torch.equal(c.double().cpu(), want), (tile, int((c.double().cpu() != want).sum()))
+
+
+def test_mnmajor_8phase_repeated_launches_bit_identical():
+    """race screen on the model's fc1 weight-gradient shape, random data, slab split-K: 10 launches agree bit for bit and
+    match float64 to float32 rounding"""
+    ops = T._ops()
+    M, N, K, split = 3072, 768, 32768, 7
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(K, M, generator=g).to(BF).cuda()
+    b = torch.randn(K, N, generator=g).to(BF).cuda()
+    outs = []
+    for it in range(10):
+        c = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        ws = torch.full((split, M, N), float("nan"), dtype=torch.float32, device="cuda")
+        ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                 split_k=split, accumulate=True, c_f32=True, splitk_ws=ws)
+        assert "gemm8pt_kernel" in _last_kernel(), _last_kernel()
+        outs.append(c)
+    for c in outs[1:]:
+        assert torch.equal(c, outs[0])
+    ref = a[:, :256].double().t() @ b.double()
+    assert (outs[0][:256].double() - ref).abs().max() <= 1e-5 * ref.abs().max()

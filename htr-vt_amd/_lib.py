@@ -106,6 +106,7 @@ PROTOTYPES = {
     "htrvt_relpos_bias_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_cast_transpose_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "htrvt_split_bf16": (i32, [vp, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp]),
+    "htrvt_elementwise_f32": (i32, [vp, vp, vp, i64, i32, vp]),
     "htrvt_class_scatter_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_sumsq_blocks": (i32, [i64]),
     "htrvt_sumsq": (i32, [vp, i64, vp, vp, vp]),

@@ -66,7 +66,12 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   if (gemm_small_m_prefers_bn128(d)) return false;      // few rows, narrow N: more, narrower tiles (gemm_dma.hip pick_bn)
   if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
   if (d->gather != HTRVT_GATHER_NONE && d->gather != HTRVT_GATHER_CONV_FWD && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;
-  if (d->split_k > 1 || d->accumulate || d->c_f32 || d->A2 != nullptr) return false;
+  if (d->split_k > 1 || d->accumulate || d->A2 != nullptr) return false;
+  // float32 C: plain Linear products only (bias at most): what the split-bf16 parity path asks for (engine.linear_fwd / _dgrad)
+  if (d->c_f32 && (d->gather != HTRVT_GATHER_NONE || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr ||
+                   d->colscale != nullptr || d->relu_src != nullptr || d->bnb_partial[0] != nullptr || d->batch > 1 ||
+                   (long long)d->M * d->ldc * 4 >= (1ll << 31) - 64))
+    return false;
   if (!extents_ok(d)) return false;
   const int bn = gemm8p_pick_bn(d);
   const int cw = bn == 256 ? 8 : 12;     // consecutive columns a lane stores
@@ -90,6 +95,10 @@ bool gemm8pt_serves(const HtrvtGemmDesc* d) {
   if (d->tile != 0 && d->tile != 16) return false;
   if (d->dtype != HTRVT_BF16 || d->gather != HTRVT_GATHER_NONE || d->a_layout != HTRVT_MNMAJOR || d->b_layout != HTRVT_MNMAJOR) return false;
   if (!d->c_f32 || d->batch > 1 || d->M < 256 || d->N < 256 || d->K < 256) return false;
+  // auto: outputs of at least 16 tiles of 256 x 256.  The proj weight gradient (768 x 768: 9 tiles) needs a 20-28-way K split to
+  // fill the chip, i.e. 18-25 k-tiles per workgroup and a 28-slab sum: measured 626 TFLOP/s at best against 741 on the
+  // one-barrier kernel's 256 x 192 tiles at split 16 (tools/bench_gemm.py --only lwgrad --tiles 0 3)
+  if (d->tile == 0 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) < 16) return false;
   if ((d->M & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return false;
   if ((reinterpret_cast<unsigned long long>(d->A) & 15) || (reinterpret_cast<unsigned long long>(d->B) & 15) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return false;
   if (d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr || d->colscale != nullptr) return false;
@@ -120,6 +129,7 @@ int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t 
   if (d->bnb_partial[0] != nullptr) epi |= E_BNB1;
   if (d->bnb_partial[1] != nullptr) epi |= E_BNB2;
   if (d->colscale != nullptr || d->act == 3) epi |= E_SCALE_RELU;
+  if (d->c_f32) epi |= E_F32;
   p.tiles_m = (d->M + 255) / 256;
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = -1;

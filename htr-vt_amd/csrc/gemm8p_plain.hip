@@ -14,6 +14,7 @@ static int by_epi(int epi, const KParams& p, int zdim, hipStream_t st) {
     case E_RES: return launch<C, 0, E_RES>(p, zdim, st);
     case E_GELU: return launch<C, 0, E_GELU>(p, zdim, st);
     case E_GELUGRAD: return launch<C, 0, E_GELUGRAD>(p, zdim, st);
+    case E_F32: return launch<C, 0, E_F32>(p, zdim, st);      // float32 C (+ bias): the Linear products of the split-bf16 parity path
     default: return 0;
   }
 }

@@ -119,7 +119,36 @@ __global__ __launch_bounds__(NT_) void class_scatter_kernel(const float* __restr
   }
 }
 
+// float32 element-wise companions of the split-bf16 Linear products (the GEMM launches write plain float32 + bias; the
+// float32 path has these steps in its GEMM epilogue, same order, same rounding points): mode 0: out = gelu_erf(a)
+// (timm Mlp, exact erf), 1: out = a * gelu_erf'(b), 2: out = a + b
+__global__ __launch_bounds__(NT_) void ew_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                     long long n4, int mode) {
+  for (long long t = (long long)blockIdx.x * NT_ + threadIdx.x; t < n4; t += (long long)gridDim.x * NT_) {
+    const f32x4_t x = reinterpret_cast<const f32x4_t*>(a)[t];
+    f32x4_t y = mode == 0 ? x : reinterpret_cast<const f32x4_t*>(b)[t];
+    f32x4_t r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (mode == 0) r[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752440f));
+      else if (mode == 1)
+        r[e] = x[e] * (0.5f * (1.0f + erff(y[e] * 0.70710678118654752440f)) + y[e] * 0.39894228040143267794f * __expf(-0.5f * y[e] * y[e]));
+      else r[e] = x[e] + y[e];
+    }
+    reinterpret_cast<f32x4_t*>(out)[t] = r;
+  }
+}
+
 }  // namespace
+
+extern "C" int htrvt_elementwise_f32(const float* a, const float* b, float* out, int64_t n, int mode, void* stream) {
+  HTRVT_REQUIRE(a != nullptr && out != nullptr && n > 0 && n % 4 == 0 && mode >= 0 && mode <= 2 && (mode == 0 || b != nullptr),
+                "htrvt_elementwise_f32: bad arguments (n %% 4 == 0; mode 0 gelu(a), 1 a * gelu'(b), 2 a + b)");
+  const long long n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + NT_ - 1) / NT_ > 65536 * 4 ? 65536 * 4 : (n4 + NT_ - 1) / NT_);
+  hipLaunchKernelGGL(ew_f32_kernel, dim3(grid), dim3(NT_), 0, (hipStream_t)stream, a, b, out, n4, mode);
+  return check_launch("elementwise_f32");
+}
 
 extern "C" int htrvt_class_scatter_f32(const float* c00, const float* c01, const float* c10, const float* c11, const float* residual,
                                        float* dx, int B, int Hi, int Wi, int C, int sh, int sw, void* stream) {

@@ -85,6 +85,7 @@ class Engine:
         assert not self.split or dtype == torch.float32, "split_bf16 is a mode of the float32 path"
         self.gdt = torch.bfloat16 if self.split else dtype
         self._split_cache = []       # backward: the few most recent (source tensor, cat, hi, lo) splits (a gradient feeds dgrad AND wgrad)
+        self._saved_planes, self._saving = {}, False    # forward(save=True): id(activation) -> its hi / lo planes, for the weight gradients
         self._packs = {}      # name -> (version key, tensors)
         self.weights_epoch = 0   # bumped by whoever rewrites parameters through raw pointers (Trainer.optimizer_step)
         self.fuse_conv1_backward = True   # conv1/bn1/maxpool backward as per-channel sums over the pooled gradient
@@ -198,15 +199,19 @@ class Engine:
         """split of an activation / gradient tensor whose innermost extent is `cols`, remembered while the backward may ask
         for it again (the same gradient is the A operand of a dgrad launch and the B operand of three wgrad launches)"""
         cur = torch.cuda.current_stream()
-        for ent in self._split_cache:
+        kept = self._saved_planes.get(id(t))      # a forward that saves for backward split this activation into planes as well
+        for ent in self._split_cache + ([kept] if kept is not None else []):
             if ent[0] is t and (ent[1] is not None or not cat) and (ent[2] is not None or not planes):
                 if ent[4] != cur:      # made on the main stream, read by a weight-gradient launch on the side stream: the
                     for u in ent[1:4]:  # caching allocator must not hand the block out again before that launch has run
                         if u is not None:
                             u.record_stream(cur)
                 return ent[1], ent[2], ent[3]
-        c, hi, lo = self._split(t, t.numel() // cols, cols, order=0, cat=cat, planes=planes)
+        want_planes = planes or self._saving      # forward of a training step: the weight gradient will want the planes of this input
+        c, hi, lo = self._split(t, t.numel() // cols, cols, order=0, cat=cat, planes=want_planes)
         self._split_cache = [e for e in self._split_cache if e[0] is not t][-2:] + [(t, c, hi, lo, cur)]
+        if self._saving:
+            self._saved_planes[id(t)] = (t, None, hi, lo, cur)
         return c, hi, lo
 
     def _lin_w_split(self, name, w):
@@ -323,11 +328,20 @@ class Engine:
     def linear_fwd(self, x, w, bias, out=None, act=0, preact=None, residual=None, c_f32=False):
         M, K = x.shape
         N = w.shape[0]
-        if self.split:      # w = (hi | hi | lo) [N][3 K]; float32 in, float32 out, the epilogue's side tensors float32
+        if self.split:      # w = (hi | hi | lo) [N][3 K]; float32 in, float32 out
             out = self._empty(M, N) if out is None else out
             xs, _, _ = self._split_act(x, K)
-            gemm(xs, w, out, dtype=self.gdt, M=M, N=N, K=3 * K, lda=3 * K, ldb=3 * K, ldc=N, bias=bias, act=act, preact=preact,
-                 residual=residual, c_f32=True)
+            # the product writes plain float32 + bias (8-phase kernel, 16-byte stores); GELU / saved pre-activation / residual
+            # are float32 element-wise passes in the float32 path's order (its GEMM epilogue): v = acc + bias; pre = v;
+            # v = gelu(v); v += residual
+            first = preact if (act == 1 and preact is not None) else out
+            gemm(xs, w, first, dtype=self.gdt, M=M, N=N, K=3 * K, lda=3 * K, ldb=3 * K, ldc=N, bias=bias, c_f32=True)
+            if act == 1:
+                check(lib.htrvt_elementwise_f32(ptr(first), None, ptr(out), M * N, 0, stream()), "elementwise_f32")
+            else:
+                assert act == 0 and preact is None
+            if residual is not None:
+                check(lib.htrvt_elementwise_f32(ptr(out), ptr(residual), ptr(out), M * N, 2, stream()), "elementwise_f32")
             return out
         if out is None:
             out = self._empty(M, N, dtype=torch.float32 if c_f32 else self.dtype)
@@ -341,8 +355,12 @@ class Engine:
         if self.split and not plain:      # wt = (hi | hi | lo) of w^T: [K][3 N]
             K = wt.shape[0]
             dx = self._empty(M, K)
-            dys, _, _ = self._split_act(dy, N, cat=True, planes=True)
-            gemm(dys, wt, dx, dtype=self.gdt, M=M, N=K, K=3 * N, lda=3 * N, ldb=3 * N, ldc=K, act=act, preact=preact, c_f32=True)
+            dys, _, _ = self._split_act(dy, N, cat=True)
+            gemm(dys, wt, dx, dtype=self.gdt, M=M, N=K, K=3 * N, lda=3 * N, ldb=3 * N, ldc=K, c_f32=True)
+            if act == 2:        # * gelu'(saved pre-activation), float32 element-wise
+                check(lib.htrvt_elementwise_f32(ptr(dx), ptr(preact), ptr(dx), M * K, 1, stream()), "elementwise_f32")
+            else:
+                assert act == 0
             return dx
         K = w.shape[1]
         dx = self._empty(M, K)
@@ -440,15 +458,18 @@ class Engine:
         M, N = dy.shape
         K = x.shape[1]
         tiling = None
-        if self.gdt == torch.bfloat16 and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0:
-            tiling = (((N + 255) // 256) * ((K + 255) // 256), 256, 256)     # the 8-phase MN-major kernel's tiles (csrc/gemm8pt_impl.h)
+        t256 = ((N + 255) // 256) * ((K + 255) // 256)
+        if self.gdt == torch.bfloat16 and self.deterministic and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0 and t256 >= 16:
+            tiling = (t256, 256, 256)     # the 8-phase MN-major kernel's tiles (csrc/gemm8pt_impl.h; gemm8pt_serves' conditions)
         sk = self._split_k(N, K, M, tiling=tiling)
         if self.split and not plain:      # the contraction runs over the rows: hi / lo planes, three accumulating launches
-            _, dyh, dyl = self._split_act(dy, N, cat=False, planes=True)
+            # MN-major plain operands carry their own leading dimension: the hi / lo planes of the gradient are column blocks
+            # 0 and 1 of the (hi | lo | hi) form the dgrad launch already made -- no second split of dy
+            dy3, _, _ = self._split_act(dy, N, cat=True, planes=False)
             _, xh, xl = self._split_act(x, K, cat=False, planes=True)
-            for a_, b_ in ((dyh, xh), (dyh, xl), (dyl, xh)):
-                gemm(a_, b_, dw, dtype=self.gdt, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
-                     split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, N, K))
+            for a_off, b_ in ((0, xh), (0, xl), (N, xh)):
+                gemm(dy3, b_, dw, dtype=self.gdt, M=N, N=K, K=M, lda=3 * N, ldb=K, ldc=K, a_layout=MNMAJOR, b_layout=MNMAJOR,
+                     split_k=sk, accumulate=True, c_f32=True, splitk_ws=self._splitk_ws(sk, N, K), a_off=a_off)
             if dbias is not None:
                 ops.colsum(dy, M, N, N, dbias, dti=self.dti)
             return
@@ -794,6 +815,7 @@ class Engine:
         st = stream()
         sv = {} if save else None
         self._split_cache = []
+        self._saved_planes, self._saving = {}, bool(save) and self.split
         C1 = s.D // 4
         keep = None
         if keep_mask is not None:   # uploaded before anything is enqueued: a pageable host->device copy waits for the stream
@@ -960,6 +982,7 @@ class Engine:
         y = self._empty(B, N, s.nb_cls, dtype=torch.float32)
         sstats = self._empty(B, 2, dtype=torch.float32)
         check(lib.htrvt_seq_whiten_fwd(ptr(raw), ptr(y), ptr(sstats), B, N * s.nb_cls, WHITEN_EPS, 0, st), "seq_whiten_fwd")
+        self._saving = False
         if save:
             sv.update(enc=enc_saved, x_last=xt, xn=xn, mn=mn, rn=rn, y=y, sstats=sstats, B=B, N=N, train=train)
             self.saved = sv
@@ -1206,4 +1229,5 @@ class Engine:
         self._side_active = False
         self._zarena_end()
         self._split_cache = []
+        self._saved_planes = {}
         self.saved = None

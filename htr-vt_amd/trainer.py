@@ -253,7 +253,9 @@ class GraphedStep:
         eng.capturing = True
         saved_single, eng.single_stream = eng.single_stream, bool(single_stream)
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: the process group's watchdog thread polls its events while we capture; under the default (global)
+            # mode such a call from ANOTHER thread invalidates the capture (seen as an abort in the one-rank RCCL test)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = tr._forward_backward_staged(self.img, (self.tg, self.tl, self.off, self.maxlen), self.keep)
                 from ._lib import check
                 from .ops import ptr, stream

@@ -323,6 +323,10 @@ int htrvt_split_bf16(const float* src, int64_t rows, int cols, int64_t ld_src, v
 /* Split-bf16 strided conv dgrad (resnet18.py:26,59-63 backward): the parity-class launches of htrvt_gemm with float32 output
  * leave one dense [B][Hq][Wq][C] matrix per class (a, b) = (hi % sh, wi % sw); this interleaves them into the NHWC gradient
  * dx [B][Hi][Wi][C] (+ residual, may be NULL).  c01 / c10 / c11 may be NULL where the stride in that direction is 1. */
+/* float32 element-wise steps beside the split-bf16 Linear products (which write plain float32 + bias): mode 0: out = gelu_erf(a)
+ * (timm Mlp's exact-erf GELU, HTR_VT.py:76), 1: out = a * gelu_erf'(b) (its backward), 2: out = a + b (residual, HTR_VT.py:81-82).
+ * The float32 path has the same steps, in the same order and with the same rounding points, inside its GEMM epilogue. */
+int htrvt_elementwise_f32(const float* a, const float* b, float* out, int64_t n, int mode, void* stream);
 int htrvt_class_scatter_f32(const float* c00, const float* c01, const float* c10, const float* c11, const float* residual, float* dx,
                             int B, int Hi, int Wi, int C, int sh, int sw, void* stream);
 

@@ -101,8 +101,9 @@ def main():
     def tn(tag, M, N, K, split):
         a, b = rnd(K, M), rnd(K, N)
         c = torch.zeros(M, N, dtype=torch.float32, device=dev)
+        ws = torch.empty(split, M, N, dtype=torch.float32, device=dev) if split > 1 else None    # slab split-K (the engine's default): incl. the ordered sum
         ms = timeit(lambda: ops.gemm(a, b, c, dtype=dt, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_layout=ops.MNMAJOR,
-                                     b_layout=ops.MNMAJOR, split_k=split, accumulate=True, c_f32=True), args.iters)
+                                     b_layout=ops.MNMAJOR, split_k=split, accumulate=True, c_f32=True, splitk_ws=ws), args.iters)
         rows.append((tag, ms, 2.0 * M * N * K))
 
     def conv(tag, B, Hi, Wi, Ci, Co, k, stride, pad):
@@ -171,7 +172,7 @@ def main():
             plain(f"qkv dgrad            {M}x768x2304", M, D, F3)
     if "lwgrad" in args.only:   # the encoder's Linear weight gradients dW[out][in] = dy^T x, K = 32768 tokens, over split factors
         for tag, Mo, No in (("fc1", 3072, 768), ("fc2", 768, 3072), ("qkv", 2304, 768), ("proj", 768, 768)):
-            for split in ((3, 4, 5, 6, 7, 8, 10, 16) if tag != "proj" else (8, 16, 24, 28, 32)):
+            for split in ((3, 4, 5, 6, 7, 8, 9, 10, 14) if tag != "proj" else (8, 12, 14, 16, 20, 24, 28)):
                 tn(f"TN wgrad-{tag} {Mo}x{No}xK32768 split {split}", Mo, No, 32768, split)
     if not args.only or "mlp" in args.only:
         M, D, F = 32768, 768, 3072

@@ -48,15 +48,22 @@ struct HwGeo {
   static __device__ __forceinline__ int xrot(int r) { return CC == 128 ? 4 * (r & 3) : 4 * ((r >> 1) & 1); }
 };
 
-template <int CC, int BN, class P>
+// PAIR (CC = 128 only): the 128-channel X tile is TWO independent 64-channel units (kernel row, 64-channel chunk) side by
+// side -- channels 0-63 of the tile are unit 2 tm, channels 64-127 unit 2 tm + 1, each read from its own image row.  For a
+// padded channel count that is a multiple of 64 but not of 128 (layer 1: 192 = three chunks x three kernel rows = nine
+// units -> five workgroups) this keeps the 384 x 192 output tile and its 41 KB per k-tile instead of falling back to
+// 192 x 192 tiles at 33 KB (CC = 64): -37 % operand bytes per FLOP for nine tenths of the MFMA work.
+template <int CC, int BN, bool PAIR, class P>
 __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) {
   using H = HwGeo<CC, BN>;
   using T = bf16_t;
   constexpr int TM = H::TM, TN = H::TN, NW = H::NW;
+  static_assert(!PAIR || CC == 128, "paired units are 64 channels wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int NCC = p.Cpad / CC;
-  const int tiles_m = 3 * NCC;                       // (kernel row, channel chunk)
+  const int NCC = PAIR ? p.Cpad / 64 : p.Cpad / CC;  // chunks per kernel row (PAIR: of 64 channels)
+  const int nunits = 3 * NCC;                        // (kernel row, channel chunk)
+  const int tiles_m = PAIR ? (nunits + 1) / 2 : nunits;
   const int ntiles = tiles_m * p.tiles_n;
   int id = block_x, z = blockIdx.z;
   if (p.split_k > 1 && (p.split_k & 7) == 0) {       // all tiles of one pixel range on one XCD (they read the same x / dY rows)
@@ -65,7 +72,17 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
     id = r >> 3;
   }
   const int tm = id / p.tiles_n, tile_n = id - tm * p.tiles_n;
-  const int dyi = tm / NCC, ci0 = (tm - dyi * NCC) * CC;
+  // unit u of this workgroup (PAIR: two, else one): kernel row dyu[u], first channel ciu[u]; a missing second unit reads zeros
+  int dyu[2], ciu[2];
+  bool uok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = PAIR ? 2 * tm + u : tm;
+    uok[u] = t < nunits;
+    const int tt = uok[u] ? t : 0;
+    dyu[u] = tt / NCC;
+    ciu[u] = (tt - dyu[u] * NCC) * (PAIR ? 64 : CC);
+  }
   const int n0 = tile_n * BN;
   int kbeg = 0, kend = p.K;
   long long coff = 0;
@@ -108,9 +125,14 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
     const unsigned sbase = lds0 + stage * H::STAGE;
     // pixel row iq_row = (image, output row ho) of dY; the x row of kernel row dyi is ho * sh + dyi - 1 (sh = 1 or 2, W stride 1)
     const int bimg = iq_row / p.Ho, hrow = iq_row - bimg * p.Ho;
-    const int hh = hrow * p.sh + dyi - 1;
-    const bool rowok = iq_k < kend && (unsigned)hh < (unsigned)Hh;
-    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + iq_w0 - 1) * p.Ci + ci0) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+    bool rowok[2];
+    unsigned gbase[2];
+#pragma unroll
+    for (int u = 0; u < (PAIR ? 2 : 1); ++u) {
+      const int hh = hrow * p.sh + dyu[u] - 1;
+      rowok[u] = uok[u] && iq_k < kend && (unsigned)hh < (unsigned)Hh;
+      gbase[u] = (unsigned)(((bimg * Hh + hh) * Ww + iq_w0 - 1) * p.Ci + ciu[u]) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+    }
 #pragma unroll
     for (int i = 0; i < H::NPX_MAX; ++i) {
       if (i < npx) {      // wave-uniform
@@ -120,8 +142,13 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
         int cs = cd - H::xrot(r);
         cs += cs < 0 ? H::XCPR : 0;
         const int w = iq_w0 - 1 + r;
-        const bool v = rowok && r < 66 && (unsigned)w < (unsigned)Ww && ci0 + cs * 8 < p.Ci;
-        const unsigned voff = v ? gbase + (unsigned)(r * p.Ci + cs * 8) * 2u : OOB;
+        const int u = PAIR ? cs >> 3 : 0;                      // which unit this 16-byte chunk belongs to
+        const int cu = PAIR ? cs & 7 : cs;                     // ... and its chunk inside the unit
+        const bool ro = PAIR ? (u ? rowok[1] : rowok[0]) : rowok[0];
+        const int ci = PAIR ? (u ? ciu[1] : ciu[0]) : ciu[0];
+        const unsigned gb = PAIR ? (u ? gbase[1] : gbase[0]) : gbase[0];
+        const bool v = ro && r < 66 && (unsigned)w < (unsigned)Ww && ci + cu * 8 < p.Ci;
+        const unsigned voff = v ? gb + (unsigned)(r * p.Ci + cu * 8) * 2u : OOB;
         dma16(rsrcX, __builtin_amdgcn_readfirstlane(sbase + pi * 1024), voff);
       }
     }
@@ -189,24 +216,26 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // rows of the packed weight gradient [tap][Cpad][Co]: m = (dy * 3 + dx) * Cpad + ci0 + channel
-  const int mrow0 = (dyi * 3 + dx) * p.Cpad + ci0 + crow;
-  gemm_epilogue<T, TM, TN, 1, BN, H::NTH, false>(acc, p, p.C, coff, mrow0, n0 + wn * TN * 32, 0, n0, 0, lane, smem, true);
+  // rows of the packed weight gradient [tap][Cpad][Co]: m = (dy * 3 + dx) * Cpad + first channel of the unit + channel
+  // (PAIR: a wave's 64 rows are one unit -- crow = 0 is unit 0, crow = 64 unit 1; an absent unit stores nothing)
+  const int un = PAIR ? (wm & 1) : 0;
+  const int mrow0 = (dyu[un] * 3 + dx) * p.Cpad + ciu[un] + (PAIR ? 0 : crow);
+  gemm_epilogue<T, TM, TN, 1, BN, H::NTH, false>(acc, p, p.C, coff, mrow0, n0 + wn * TN * 32, 0, n0, 0, lane, smem, uok[un]);
 }
 
-template <int CC, int BN>
+template <int CC, int BN, bool PAIR = false>
 __global__ __launch_bounds__(768) void gemm_hwgrad_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;
   (void)p;
   KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
-  gemm_hwgrad_body<CC, BN>(*kp, (int)blockIdx.x);
+  gemm_hwgrad_body<CC, BN, PAIR>(*kp, (int)blockIdx.x);
 }
 
-template <int CC, int BN>
+template <int CC, int BN, bool PAIR = false>
 int launch_hwgrad(const KParams& p, int zdim, hipStream_t st) {
   using H = HwGeo<CC, BN>;
   static bool attr_done = false;
-  auto kern = gemm_hwgrad_kernel<CC, BN>;
+  auto kern = gemm_hwgrad_kernel<CC, BN, PAIR>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
     if (e != hipSuccess) {
@@ -215,11 +244,11 @@ int launch_hwgrad(const KParams& p, int zdim, hipStream_t st) {
     }
     attr_done = true;
   }
-  const int ntiles = 3 * (p.Cpad / CC) * p.tiles_n;
+  const int ntiles = (PAIR ? (3 * (p.Cpad / 64) + 1) / 2 : 3 * (p.Cpad / CC)) * p.tiles_n;
   dim3 grid(ntiles, 1, zdim);
   if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
-  set_last_kernel("gemm_hwgrad_kernel<%d, %d>", CC, BN);
+  set_last_kernel(PAIR ? "gemm_hwgrad_kernel<%d, %d, true>" : "gemm_hwgrad_kernel<%d, %d>", CC, BN);
   const int rc = check_launch("gemm_hwgrad_kernel");
   return rc ? rc : 1;
 }

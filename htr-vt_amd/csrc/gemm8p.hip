@@ -93,6 +93,8 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
 // schedule with transposed fragment reads (gemm8pt_impl.h).  tile 0 (auto) and 16; 3 / 4 / 6 keep naming the older kernels.
 bool gemm8pt_serves(const HtrvtGemmDesc* d) {
   if (d->tile != 0 && d->tile != 16) return false;
+  static const bool off = getenv("HTRVT_NO_MNMAJOR_8PHASE") != nullptr && getenv("HTRVT_NO_MNMAJOR_8PHASE")[0] == '1';   // A/B runs on one box
+  if (off && d->tile == 0) return false;
   if (d->dtype != HTRVT_BF16 || d->gather != HTRVT_GATHER_NONE || d->a_layout != HTRVT_MNMAJOR || d->b_layout != HTRVT_MNMAJOR) return false;
   if (!d->c_f32 || d->batch > 1 || d->M < 256 || d->N < 256 || d->K < 256) return false;
   // auto: outputs of at least 16 tiles of 256 x 256.  The proj weight gradient (768 x 768: 9 tiles) needs a 20-28-way K split to

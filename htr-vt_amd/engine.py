@@ -459,7 +459,8 @@ class Engine:
         K = x.shape[1]
         tiling = None
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
-        if self.gdt == torch.bfloat16 and self.deterministic and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0 and t256 >= 16:
+        if (self.gdt == torch.bfloat16 and self.deterministic and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0 and t256 >= 16
+                and os.environ.get("HTRVT_NO_MNMAJOR_8PHASE") != "1"):
             tiling = (t256, 256, 256)     # the 8-phase MN-major kernel's tiles (csrc/gemm8pt_impl.h; gemm8pt_serves' conditions)
         sk = self._split_k(N, K, M, tiling=tiling)
         if self.split and not plain:      # the contraction runs over the rows: hi / lo planes, three accumulating launches

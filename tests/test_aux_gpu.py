@@ -192,3 +192,41 @@ def test_split_bf16_forms(rows, cols):
         h2, l2 = torch.empty(rows, cols, dtype=BF, device="cuda"), torch.empty(rows, cols, dtype=BF, device="cuda")
         check(lib.htrvt_split_bf16(ptr(x), rows, cols, cols, None, 0, 0, 0, ptr(h2), ptr(l2), stream()))
         assert torch.equal(h2, hi) and torch.equal(l2, lo)
+
+
+def test_elementwise_f32_steps():
+    """htrvt_elementwise_f32: the float32 GELU / GELU' / residual steps beside the split-bf16 Linear products, against
+    torch's float64 erf GELU and its autograd derivative"""
+    from htrvt_amd._lib import check, lib
+    from htrvt_amd.ops import ptr, stream
+    g = torch.Generator().manual_seed(1)
+    a = (torch.randn(1000, 768, generator=g) * 2).cuda()
+    b = (torch.randn(1000, 768, generator=g) * 2).cuda()
+    out = torch.empty_like(a)
+    check(lib.htrvt_elementwise_f32(ptr(a), None, ptr(out), a.numel(), 0, stream()))
+    assert (out.double() - torch.nn.functional.gelu(a.double())).abs().max() < 2e-6
+    bd = b.double().requires_grad_(True)
+    torch.nn.functional.gelu(bd).sum().backward()
+    check(lib.htrvt_elementwise_f32(ptr(a), ptr(b), ptr(out), a.numel(), 1, stream()))
+    assert (out.double() - a.double() * bd.grad).abs().max() < 1e-5
+    check(lib.htrvt_elementwise_f32(ptr(a), ptr(b), ptr(out), a.numel(), 2, stream()))
+    assert torch.equal(out, a + b)
+    check(lib.htrvt_elementwise_f32(ptr(out), ptr(b), ptr(out), a.numel(), 2, stream()))      # in place
+    assert torch.equal(out, (a + b) + b)
+
+
+@pytest.mark.parametrize("sh,sw,Hi,Wi", [(2, 2, 8, 64), (2, 1, 16, 32), (2, 2, 7, 33)])
+def test_class_scatter_f32(sh, sw, Hi, Wi):
+    """htrvt_class_scatter_f32: dense per-parity-class matrices -> the NHWC gradient (+ residual), odd extents included"""
+    from htrvt_amd._lib import check, lib
+    from htrvt_amd.ops import ptr, stream
+    B, C = 3, 24
+    g = torch.Generator().manual_seed(sh * 10 + sw)
+    full = torch.randn(B, Hi, Wi, C, generator=g).cuda()
+    res = torch.randn(B, Hi, Wi, C, generator=g).cuda()
+    parts = {(a, b): full[:, a::sh, b::sw, :].contiguous() for a in range(sh) for b in range(sw)}
+    dx = torch.full_like(full, float("nan"))
+    for r in (None, res):
+        check(lib.htrvt_class_scatter_f32(ptr(parts[(0, 0)]), ptr(parts.get((0, 1))), ptr(parts.get((1, 0))), ptr(parts.get((1, 1))),
+                                          ptr(r), ptr(dx), B, Hi, Wi, C, sh, sw, stream()))
+        assert torch.equal(dx, full if r is None else full + res)

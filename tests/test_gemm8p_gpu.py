@@ -496,3 +496,19 @@ def test_mnmajor_8phase_repeated_launches_bit_identical():
         assert torch.equal(c, outs[0])
     ref = a[:, :256].double().t() @ b.double()
     assert (outs[0][:256].double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 2304), (1000, 264, 200), (4096, 3072, 192)])
+def test_plain_float32_output_exact(tile, M, N, K):
+    """float32 C straight from the accumulators (+ bias): the Linear products of the split-bf16 parity path"""
+    ops = T._ops()
+    A, B = T._ints((M, K), seed=31), T._ints((N, K), seed=32)
+    bias = T._ints((N,), lo=-9, hi=10, seed=33)
+    a, b = A.to(BF).cuda(), B.to(BF).cuda()
+    c = torch.full((M, N + 4), 3.0, dtype=torch.float32, device="cuda")
+    ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 4, bias=bias.float().cuda(), c_f32=True, tile=tile)
+    assert "gemm8p_kernel" in _last_kernel() and ", 128>" in _last_kernel(), _last_kernel()
+    got = c.double().cpu()
+    assert torch.equal(got[:, :N], A @ B.t() + bias)
+    assert (got[:, N:] == 3.0).all()

@@ -333,3 +333,43 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
         got = parts[t].double().cpu()
         assert got.shape == want.shape, (got.shape, want.shape)
         assert torch.equal(got, want), (t, float((got - want).abs().max()))
+
+
+@pytest.mark.parametrize("ratio", [1.0, 60.0, 100.0])
+def test_conv_dgrad_fused_bn_sums_large_mean(ratio):
+    """the fused BatchNorm-backward sums accumulate RAW sum g*x per tile and centre once at the end, (q - mean*a)*rstd, in
+    float32: with |channel mean| >> std that is a difference of two large numbers (advisor, round 3).  Random float data
+    with channel means of `ratio` standard deviations against float64: the per-tile sums must stay within 1e-3 of
+    sum |g * xhat| -- three decimal digits are plenty for a gradient of gamma -- at every ratio."""
+    import htrvt_amd
+    from htrvt_amd.engine import Engine, ModelShape
+    ops = _ops()
+    dtype = torch.bfloat16
+    Bn, Hi, Wi, Ci, Co = 2, 8, 256, 192, 192
+    eng = Engine(ModelShape(80, (64, 512), 64, 2, 2), dtype, "cuda")
+    geom = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, 3, (1, 1), 1)
+    gen = torch.Generator().manual_seed(7)
+    w = _sparse_ints((Co, Ci, 3, 3), 40)
+    dy = _sparse_ints((Bn, Co, geom.Ho, geom.Wo), 41)
+    dx = torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), w, dy, stride=1, padding=1).permute(0, 2, 3, 1)
+    relu_src = _ints((Bn, Hi, Wi, Ci), -1, 2, seed=43)
+    g_ref = dx * (relu_src > 0)
+    std = torch.rand(Ci, generator=gen).double() * 2 + 0.5
+    mean = (torch.randint(0, 2, (Ci,), generator=gen).double() * 2 - 1) * ratio * std
+    x = (torch.randn(Bn, Hi, Wi, Ci, generator=gen).double() * std + mean).to(dtype)       # the values the kernel reads
+    rstd = 1.0 / std
+    wd = _pack_dgrad(w, ops.cpad(Co, dtype)).to(dtype).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    rows = eng.dgrad_tiles(geom)
+    part = torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda")
+    out = eng.conv_dgrad(dyd, wd, geom, relu_src=relu_src.to(dtype).cuda(),
+                         bnb=[(x.cuda(), mean.float().cuda(), rstd.float().cuda(), part)])
+    assert torch.equal(out.double().cpu(), g_ref)
+    xhat = (x.double() - mean.float().double()) * rstd.float().double()
+    gg, xx = g_ref.reshape(-1, Ci), xhat.reshape(-1, Ci)
+    want = torch.stack([(gg[r0:r0 + 256] * xx[r0:r0 + 256]).sum(0) for r0 in range(0, gg.shape[0], 256)])
+    scale = torch.stack([(gg[r0:r0 + 256] * xx[r0:r0 + 256]).abs().sum(0) for r0 in range(0, gg.shape[0], 256)]).clamp_min(1.0)
+    got = part[:, 1].double().cpu()
+    err = ((got - want).abs() / scale).max().item()
+    print(f"mean / std = {ratio}: worst |sum g xhat error| / sum |g xhat| = {err:.2e}")
+    assert err < 1e-3, err

@@ -23,7 +23,7 @@ timeout -k 10 300 python bench.py --width 2048 --batch 64 --no-cpu-baseline --no
 timeout -k 10 300 python bench.py --embed-dim 512 --depth 12 --heads 8 --nb-cls 90 --batch 32 --no-cpu-baseline --no-parity-path > $O/cfg5_bf16.json 2> $O/cfg5_bf16.err; echo "cfg5 bf16 rc=$?"
 timeout -k 10 300 python bench.py --embed-dim 512 --depth 12 --heads 8 --nb-cls 90 --batch 32 --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline > $O/cfg5_f32.json 2> $O/cfg5_f32.err; echo "cfg5 f32 rc=$?"
 timeout -k 10 300 python bench.py --sam --no-cpu-baseline --no-parity-path > $O/sam.json 2> $O/sam.err; echo "sam rc=$?"
-timeout -k 10 300 python bench.py --dtype split_bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-path > $O/split_bf16.json 2> $O/split_bf16.err; echo "split rc=$?"
+timeout -k 10 300 python bench.py --dtype split_bf16 --steps 3 --warmup 3 --no-cpu-baseline --no-parity-path > $O/split_bf16.json 2> $O/split_bf16.err; echo "split rc=$?"
 for b in 128 16; do timeout -k 10 300 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --no-parity-path --graph on > $O/graph_b$b.json 2> $O/graph_b$b.err; echo "graph b$b rc=$?"; done
 timeout -k 10 600 python tools/bench_gemm.py --only enc --tiles 9 0 --rounds 3 > $O/enc_ab.log 2>&1; echo "enc ab rc=$?"
 timeout -k 10 600 python tools/bench_gemm.py --only lwgrad --tiles 3 0 --rounds 2 > $O/lwgrad_ab.log 2>&1; echo "lwgrad ab rc=$?"

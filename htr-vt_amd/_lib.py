@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
         ("alpha", f32), ("act", i32), ("c_f32", i32), ("accumulate", i32), ("tile", i32),
         ("bias", vp), ("colscale", vp), ("preact", vp), ("residual", vp), ("colstats", vp),
         ("relu_src", vp), ("bnb_x", vp * 2), ("bnb_mean", vp * 2), ("bnb_rstd", vp * 2), ("bnb_partial", vp * 2),
-        ("bnb_tile0", i32), ("relu_scale", vp), ("relu_shift", vp),
+        ("bnb_tile0", i32), ("relu_scale", vp), ("relu_shift", vp), ("relu_bits", i32),
         ("A", vp), ("B", vp), ("C", vp),
     ]
 
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "htrvt_bn_finalize": (i32, [vp, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "htrvt_bn_eval_coeffs": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, vp]),
     "htrvt_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "htrvt_bn_apply_mask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "htrvt_bn_relu_maxpool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_pool_tokens": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "htrvt_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),

@@ -472,6 +472,11 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   p.tiles_n = (d->N + bn - 1) / bn;
   p.wo_shift = p.howo_shift = p.wq_shift = p.hwq_shift = -1;
   p.relu_src = (const char*)d->relu_src;
+  p.relu_bits = d->relu_bits;
+  HTRVT_REQUIRE(d->relu_bits == 0 || (d->relu_src != nullptr && d->bnb_partial[0] != nullptr && d->relu_scale == nullptr &&
+                                      d->gather == HTRVT_GATHER_CONV_DGRAD && d->dtype == HTRVT_BF16 && d->batch <= 1 && (d->ldc & 7) == 0 &&
+                                      !(d->residual == nullptr && d->bnb_partial[1] != nullptr)),
+                "htrvt_gemm: relu_bits needs a bfloat16 conv dgrad with relu_src, one BatchNorm sum set (or a residual and two), ldc a multiple of 8");
   for (int t = 0; t < 2; ++t) {
     p.bnb_x[t] = (const char*)d->bnb_x[t];
     p.bnb_mean[t] = d->bnb_mean[t];

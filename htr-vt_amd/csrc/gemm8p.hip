@@ -83,7 +83,7 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   if (d->act == 2 && d->preact == nullptr) return false;
   if ((d->colscale != nullptr || d->act == 3) && d->gather != HTRVT_GATHER_CONV_FWD) return false;
   if ((d->relu_src != nullptr || d->bnb_partial[0] != nullptr) && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;
-  if (d->relu_scale != nullptr) return false;       // mask recomputed from the BatchNorm input: staged epilogue only
+  if (d->relu_scale != nullptr || d->relu_bits != 0) return false;       // mask recomputed from the BatchNorm input / bit mask: staged epilogue only
   if (d->colstats != nullptr && d->gather != HTRVT_GATHER_CONV_FWD) return false;
   if (d->act != 1 && d->act != 2 && d->preact != nullptr) return false;   // pre-activation without GELU: not built
   return true;

@@ -55,6 +55,7 @@ struct KParams {
   unsigned extra_off;
   // fused backward-of-ReLU and BatchNorm-backward column sums in the bf16 staged epilogue (conv dgrad outputs)
   const char* relu_src;
+  int relu_bits;              // relu_src is a bit mask: bit (m * ldc + n) & 7 of byte (m * ldc + n) >> 3 (HtrvtGemmDesc.relu_bits)
   const char* bnb_x[2];
   const float* bnb_mean[2];
   const float* bnb_rstd[2];

@@ -414,6 +414,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   bf16_t* const Cb = reinterpret_cast<bf16_t*>(p.C) + coff;
   const bf16_t* const resb = reinterpret_cast<const bf16_t*>(p.residual) + coff;
   const bf16_t* const relub = reinterpret_cast<const bf16_t*>(p.relu_src) + coff;
+  const unsigned char* const relubits = reinterpret_cast<const unsigned char*>(p.relu_src) + (coff >> 3);   // the 1-bit form (p.relu_bits)
   bf16_t* const preb = reinterpret_cast<bf16_t*>(p.preact) + coff;
   const bf16_t* const bx0 = reinterpret_cast<const bf16_t*>(p.bnb_x[0]) + coff;
   const bf16_t* const bx1 = reinterpret_cast<const bf16_t*>(p.bnb_x[1]) + coff;
@@ -434,12 +435,13 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
     const bool has_res = FRES == 1 || (FRES == 2 && rt_res);
     const bool has_relu = FRELU == 1 || (FRELU == 2 && rt_relu);
     constexpr bool RELU_X = FRELU == 3;       // mask from bnb_x[0] through (rsc, rsf); needs FNB >= 1
+    constexpr bool RELU_BITS = FRELU == 4;    // one mask byte per item and lane instead of 16 bytes of the activation
     const bool has_pre_in = FPIN == 1 || (FPIN == 2 && rt_pre_in);
     const bool has_pre_out = FPOUT == 1 || (FPOUT == 2 && rt_pre_out);
     const bool has_gelu = FGELU == 1 || (FGELU == 2 && rt_gelu);
     const int nb = FNB == 3 ? rt_nb : FNB;
     const bool relu_last = FRLAST == 1 || (FRLAST == 2 && rt_rlast);
-    const bool ew = has_res || has_relu || RELU_X || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
+    const bool ew = has_res || has_relu || RELU_X || RELU_BITS || has_pre_in || has_gelu || nb > 0 || relu_last;   // any arithmetic on the staged values
     // ReLU-from-BatchNorm-input variant (one side input per item): the x vectors of BOTH rounds are requested before the
     // first round is processed -- one exposed memory round trip per tile instead of two (the accumulators are dead here, the
     // 32 registers are free).  Items of round 0 / 1 sit in two named sets, selected per round (no dynamic register index).
@@ -463,6 +465,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
       unsigned o[U];
       bool ok[U];
       uint4 rres[U], rrelu[U], rpre[U], rbx[2][U], raw[U];
+      unsigned rbits[U];
       const bool first_round = id0 == wave;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -493,6 +496,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
         o[u] = ok[u] ? (unsigned)m * ldc + (unsigned)nbc : 0u;   // element 0 is a valid address of every operand
         if (has_res) rres[u] = *reinterpret_cast<const uint4*>(resb + o[u]);
         if (has_relu) rrelu[u] = *reinterpret_cast<const uint4*>(relub + o[u]);
+        if constexpr (RELU_BITS) rbits[u] = relubits[o[u] >> 3];
         if (has_pre_in) rpre[u] = *reinterpret_cast<const uint4*>(preb + o[u]);
         if constexpr (PRE) {
           const uint4 a_ = pbx0[u], b_ = pbx1[u];
@@ -557,6 +561,11 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
         }
+        if constexpr (RELU_BITS) {  // the same decision, one bit per element (written by htrvt_bn_apply_mask in the forward pass)
+          const unsigned rb = rbits[u];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((rb >> e) & 1u) ? v[e] : 0.f;
+        }
         if constexpr (RELU_X) {  // the same ReLU, its input rebuilt from the BatchNorm input that is loaded for the sums anyway
           const uint4 xr = rbx[0][u];
           const float x[8] = {bf16lo(xr.x), bf16hi(xr.x), bf16lo(xr.y), bf16hi(xr.y),
@@ -592,8 +601,14 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
   if constexpr (DGRAD) {   // conv dgrad: [residual] [ReLU mask + 1 or 2 BatchNorm-backward sum sets]
     if (relux) walk(I0{}, I3{}, I0{}, I0{}, I0{}, I1{}, I0{});      // host guarantees: one bnb set, no residual, no relu_src
+    else if (rt_relu && p.relu_bits) {   // host guarantees: relu_src + (1 set | residual + 1 set | residual + 2 sets), nothing else
+      if (!rt_res) walk(I0{}, I4{}, I0{}, I0{}, I0{}, I1{}, I0{});
+      else if (rt_nb == 1) walk(I1{}, I4{}, I0{}, I0{}, I0{}, I1{}, I0{});
+      else walk(I1{}, I4{}, I0{}, I0{}, I0{}, I2{}, I0{});
+    }
     else if (!rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I0{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
     else if (rt_res && !rt_relu && rt_nb == 0 && !rt_rlast) walk(I1{}, I0{}, I0{}, I0{}, I0{}, I0{}, I0{});
     else if (!rt_res && rt_relu && rt_nb == 1 && !rt_rlast) walk(I0{}, I1{}, I0{}, I0{}, I0{}, I1{}, I0{});

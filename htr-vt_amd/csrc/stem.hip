@@ -560,11 +560,14 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // ------------------------------------------------------------------ BN apply (+residual, +ReLU)
 // The per-channel coefficients sit in LDS and the channel index of a thread's vector advances by a constant per grid
 // stride (per element loads from global and a 64-bit modulo per vector were most of the kernel's instructions).
-template <typename T, int RES>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
+// MASK (bfloat16, 8 elements per vector): byte i of `mask` = the signs of vector i's outputs, bit j set where y[8 i + j] > 0
+// -- the ReLU's backward reads this bit instead of y (HtrvtGemmDesc.relu_bits).
+template <typename T, int RES, bool MASK = false>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                      T* __restrict__ y, long long nvec, int C, int relu) {
+                                                      T* __restrict__ y, long long nvec, int C, int relu,
+                                                      unsigned char* __restrict__ mask = nullptr) {
   constexpr int CH = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sco[];   // [2 or 4][C]: scale, shift [, rscale, rshift]
   for (int k = threadIdx.x; k < C; k += NT) {
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
     Vec16<T> v, r, o;
     v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[i];
     if constexpr (RES != 0) r.raw = reinterpret_cast<const decltype(r.raw)*>(res)[i];
+    unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float a = fmaf(v.get(j), ca[j], ca[C + j]);
@@ -593,8 +597,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
       if constexpr (RES == 2) a += fmaf(r.get(j), ca[2 * C + j], ca[3 * C + j]);
       if (relu) a = fmaxf(a, 0.f);
       o.set(j, a);
+      if constexpr (MASK) bits |= (o.get(j) > 0.f ? 1u : 0u) << j;     // of the ROUNDED output: what a reader of y would see
     }
     reinterpret_cast<decltype(o.raw)*>(y)[i] = o.raw;
+    if constexpr (MASK) mask[i] = (unsigned char)bits;
     cv += step;
     if (cv >= cvec) cv -= cvec;
   }
@@ -871,6 +877,25 @@ extern "C" int htrvt_bn_apply(const void* x, const float* scale, const float* sh
   }
 #undef LAUNCH_BN_APPLY
   return check_launch("bn_apply");
+}
+
+extern "C" int htrvt_bn_apply_mask(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                                   const float* rshift, void* y, uint8_t* mask, int64_t npix, int C, int relu, int dtype,
+                                   void* stream) {
+  HTRVT_REQUIRE(dtype == HTRVT_BF16 && mask != nullptr, "htrvt_bn_apply_mask: bfloat16 tensors and a mask buffer");
+  HTRVT_REQUIRE(C % 8 == 0, "htrvt_bn_apply_mask: C=%d must be a multiple of 8", C);
+  const long long nvec = npix * (C / 8);
+  const int mode = res == nullptr ? 0 : (rscale == nullptr ? 1 : 2);
+  dim3 grid(grid_for(nvec));
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BN_APPLY_MASK(R)                                                                                              \
+  hipLaunchKernelGGL((bn_apply_kernel<bf16_t, R, true>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st,   \
+                     (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, (bf16_t*)y, nvec, C, relu, mask)
+  if (mode == 0) LAUNCH_BN_APPLY_MASK(0);
+  else if (mode == 1) LAUNCH_BN_APPLY_MASK(1);
+  else LAUNCH_BN_APPLY_MASK(2);
+#undef LAUNCH_BN_APPLY_MASK
+  return check_launch("bn_apply_mask");
 }
 
 extern "C" int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int B,

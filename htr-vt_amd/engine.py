@@ -108,6 +108,7 @@ class Engine:
         # bf16: every conv / Linear weight is re-packed by ONE table-driven launch per step and the conv weight gradients are
         # unpacked by one launch per DP bucket (csrc/relayout.hip) instead of one launch per tensor (47 per step)
         self.table_relayout = True
+        self.relu_bitmask = True        # a block's output ReLU: the forward BatchNorm pass writes its 1-bit mask, the fused dgrad reads that instead of the activation
         self.relu_mask_from_bn = True   # conv2's fused dgrad epilogue: ReLU mask from the BatchNorm input it reads anyway (no read of a1)
         self.merge_bn_backward = True   # first block of a stage: bn2 + downsample-BN backward in one pass over the shared gradient
         self._pending_unpack = []
@@ -528,7 +529,7 @@ class Engine:
     def _dgrad_by_class(self, g):
         return self.gdt == torch.bfloat16 and (g.sh, g.sw) != (1, 1) and g.B * g.Hi * g.Wi // (g.sh * g.sw) > 128
 
-    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None, relu_bn=None):
+    def conv_dgrad(self, dy, wd, g: ConvGeom, residual=None, relu_src=None, bnb=None, extra=None, relu_bn=None, relu_bits=False):
         """dx = conv-dgrad(dy) [+ residual] [masked by relu_src > 0]; bnb: fused BatchNorm-backward sums (bf16 only).
         extra = dy2 (parity-class path only): the gradient of the block's 1x1 downsample conv output, allocated right
         behind dy; wd is then the joint pack of _conv_w_joint_dgrad and dx also receives the 1x1 conv's input gradient."""
@@ -585,7 +586,7 @@ class Engine:
                     with torch.cuda.stream(st_):
                         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * Hq * Wq, N=g.Ci, K=(nt + (1 if a2 is not None else 0)) * cpo,
                              lda=g.Co, ldb=wtaps * cpo, ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual,
-                             cls=(a, b), relu_src=relu_src, bnb=bnb, bnb_tile0=tile0, a2=a2)
+                             cls=(a, b), relu_src=relu_src, relu_bits=relu_bits, bnb=bnb, bnb_tile0=tile0, a2=a2)
                     tile0 += ops.gemm_num_mtiles(g.B * Hq * Wq, g.Ci, self.dtype, gather=GATHER_CONV_DGRAD)
             for st_ in used:       # every class has written its pixels before anything downstream reads dx
                 main.wait_stream(st_)
@@ -605,7 +606,8 @@ class Engine:
                      a_off=c * Bc * g.Ho * g.Wo * 3 * g.Co, c_off=c * Mc * g.Ci)
             return dx
         gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=g.taps * cpo, lda=g.Co, ldb=g.taps * cpo,
-             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, bnb=bnb, relu_bn=relu_bn)
+             ldc=g.Ci, gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, relu_src=relu_src, relu_bits=relu_bits, bnb=bnb,
+             relu_bn=relu_bn)
         return dx
 
     def _conv_wgrad(self, dy, x, g: ConvGeom, dw):
@@ -718,9 +720,16 @@ class Engine:
               "bn_eval_coeffs")
         return scale, shift, (P[prefix + ".running_mean"] if save else None), rstd
 
-    def bn_apply(self, x, scale, shift, relu, res=None, rscale=None, rshift=None):
+    def bn_apply(self, x, scale, shift, relu, res=None, rscale=None, rshift=None, want_mask=False):
+        """y = [relu](x * scale + shift [+ res [* rscale + rshift]]); want_mask: also the 1-bit-per-element sign mask of y
+        (uint8 [numel / 8]) that the backward of this ReLU reads instead of y (HtrvtGemmDesc.relu_bits)"""
         y = torch.empty_like(x)
         C = x.shape[-1]
+        if want_mask:
+            mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+            check(lib.htrvt_bn_apply_mask(ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(rscale), ptr(rshift), ptr(y), ptr(mask),
+                                          x.numel() // C, C, 1 if relu else 0, self.dti, stream()), "bn_apply_mask")
+            return y, mask
         check(lib.htrvt_bn_apply(ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(rscale), ptr(rshift), ptr(y),
                                  x.numel() // C, C, 1 if relu else 0, self.dti, stream()), "bn_apply")
         return y
@@ -922,13 +931,17 @@ class Engine:
                     wfd, _ = self._conv_w(p + ".downsample.0", P[p + ".downsample.0.weight"])
                     cd, csd, rd = self.conv_fwd(x, wfd, gd, train)
                     bn_d = self.bn_coeffs(P, p + ".downsample.1", planes, train, csd, rd, B * gd.Ho * gd.Wo, save=save)
-                    out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, res=cd, rscale=bn_d[0], rshift=bn_d[1])
+                    res_kw = dict(res=cd, rscale=bn_d[0], rshift=bn_d[1])
                 else:
                     gd, cd, bn_d = None, None, None
-                    out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, res=x)
+                    res_kw = dict(res=x)
+                # the block's output ReLU: its backward (fused into the NEXT block's conv1 dgrad) reads one bit per element
+                want_mask = bool(save and self.relu_bitmask and self.fuse_bn_backward and self.dtype == torch.bfloat16 and planes % 8 == 0)
+                out = self.bn_apply(cb, bn_b[0], bn_b[1], relu=True, want_mask=want_mask, **res_kw)
+                out, omask = out if want_mask else (out, None)
                 if save:
                     blocks_saved.append(dict(p=p, x=x, g1=g1, ca=ca, bn_a=bn_a, a1=a1, g2=g2, cb=cb, bn_b=bn_b, gd=gd, cd=cd,
-                                             bn_d=bn_d, out=out))
+                                             bn_d=bn_d, out=out, mask=omask))
                 x = out
                 Hc, Wc, Cin = g1.Ho, g1.Wo, planes
 
@@ -1180,6 +1193,10 @@ class Engine:
                 req = bnb_of(prev, Cp)
                 bufs = [self._empty(rows, 2, Cp, dtype=torch.float32) for _ in req]
                 kw = dict(relu_src=prev["out"], bnb=[(x_, m_, r_, b_) for (x_, m_, r_), b_ in zip(req, bufs)])
+                # the bit-mask form is compiled for (one sum set) and (residual + one or two sets)
+                with_res = not (blk["gd"] is not None and fuse_ds)
+                if prev.get("mask") is not None and (len(req) == 1 or with_res):
+                    kw.update(relu_src=prev["mask"], relu_bits=True)
                 parts = [(b_, rows) for b_ in bufs]
             if blk["gd"] is not None:
                 dcd_out = pair[1] if fuse_ds else None

@@ -67,7 +67,8 @@ class ConvGeom:
 def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, gather=0, geom=None,
          Cpad=0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=1, alpha=1.0, act=0, c_f32=False,
          accumulate=False, bias=None, colscale=None, preact=None, residual=None, colstats=None, tile=0,
-         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0, splitk_ws=None, a2=None, relu_bn=None):
+         a_off=0, b_off=0, c_off=0, cls=None, relu_src=None, bnb=None, bnb_tile0=0, splitk_ws=None, a2=None, relu_bn=None,
+         relu_bits=False):
     """Enqueue one htrvt_gemm.  A/B/Cout are tensors (only their storage pointer
     is used); *_off are element offsets into them."""
     d = GemmDesc()
@@ -97,6 +98,7 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     d.residual = ptr(residual)
     d.colstats = ptr(colstats)
     d.relu_src = ptr(relu_src)
+    d.relu_bits = 1 if relu_bits else 0      # relu_src is the bit mask written by htrvt_bn_apply_mask
     if relu_bn is not None:     # (scale, shift) of the BatchNorm in front of the ReLU: mask recomputed from bnb[0]'s x
         d.relu_scale, d.relu_shift = ptr(relu_bn[0]), ptr(relu_bn[1])
     if bnb:     # [(x, mean, rstd, partial), ...] up to two BatchNorm layers fed by this gradient

@@ -104,6 +104,10 @@ typedef struct HtrvtGemmDesc {
   int32_t bnb_tile0;
   const float* relu_scale;
   const float* relu_shift;
+  /* 1: relu_src is a BIT mask instead of the activation itself -- bit (m * ldc + n) of the byte array, i.e. one byte per
+   * 8 consecutive columns of a row, set where the ReLU's output was positive (htrvt_bn_apply_mask writes it in the forward
+   * pass): 1/16 of the side-input bytes of the fused dgrad epilogue (403 -> 25 MB per layer-1 launch) */
+  int32_t relu_bits;
   const void* A;
   const void* B;
   void* C;
@@ -152,6 +156,11 @@ int htrvt_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
 /* y = [relu]( x*scale+shift [+ (res*rscale+rshift | res)] ), NHWC, any number of pixels */
 int htrvt_bn_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
                    const float* rshift, void* y, int64_t npix, int C, int relu, int dtype, void* stream);
+/* the same pass, additionally writing the ReLU bit mask of y: mask[i >> 3] bit (i & 7) = (y[i] > 0) over the flattened
+ * [npix][C] output (C a multiple of 8; bfloat16 only) -- the `relu_bits` side input of the dgrad launch that takes the
+ * backward of this ReLU (HtrvtGemmDesc.relu_bits), so that the backward reads 1 bit instead of 16 per element */
+int htrvt_bn_apply_mask(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                        const float* rshift, void* y, uint8_t* mask, int64_t npix, int C, int relu, int dtype, void* stream);
 /* y = maxpool3x3 stride (2,1) pad 1 ( relu(x*scale+shift) ), NHWC; scale==NULL: plain maxpool of x.
  * idx (uint8 per output element, window position 0..8 of the FIRST maximum in scan order, as ATen) or NULL */
 int htrvt_bn_relu_maxpool(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,

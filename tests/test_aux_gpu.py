@@ -230,3 +230,32 @@ def test_class_scatter_f32(sh, sw, Hi, Wi):
         check(lib.htrvt_class_scatter_f32(ptr(parts[(0, 0)]), ptr(parts.get((0, 1))), ptr(parts.get((1, 0))), ptr(parts.get((1, 1))),
                                           ptr(r), ptr(dx), B, Hi, Wi, C, sh, sw, stream()))
         assert torch.equal(dx, full if r is None else full + res)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 8, 256, 192), (1, 3, 37, 384)])
+def test_bn_apply_mask_is_the_sign_of_the_output(mode, shape):
+    """htrvt_bn_apply_mask = htrvt_bn_apply + the 1-bit ReLU mask of the output (one byte per 8 channels, bit j = element
+    8 i + j > 0): the output must equal the mask-free pass bit for bit and the mask must be the sign of the STORED output"""
+    import numpy as np
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd._lib import check, lib
+    from htrvt_amd.ops import dt, ptr, stream
+    torch.manual_seed(5)
+    bf = dt(torch.bfloat16)
+    C = shape[-1]
+    x = torch.randn(*shape, device="cuda").bfloat16()
+    res = torch.randn(*shape, device="cuda").bfloat16() if mode else None
+    sc, sf = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    rsc, rsf = (torch.randn(C, device="cuda"), torch.randn(C, device="cuda")) if mode == 2 else (None, None)
+    npix = x.numel() // C
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    mask = torch.zeros(x.numel() // 8, dtype=torch.uint8, device="cuda")
+    check(lib.htrvt_bn_apply(ptr(x), ptr(sc), ptr(sf), ptr(res), ptr(rsc), ptr(rsf), ptr(y0), npix, C, 1, bf, stream()), "bn_apply")
+    check(lib.htrvt_bn_apply_mask(ptr(x), ptr(sc), ptr(sf), ptr(res), ptr(rsc), ptr(rsf), ptr(y1), ptr(mask), npix, C, 1, bf, stream()),
+          "bn_apply_mask")
+    assert torch.equal(y0, y1)
+    want = np.packbits((y0.float() > 0).cpu().numpy().reshape(-1), bitorder="little")
+    assert np.array_equal(mask.cpu().numpy(), want)
+    frac = float((y0.float() > 0).float().mean())
+    assert 0.2 < frac < 0.8

@@ -334,6 +334,18 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
         assert got.shape == want.shape, (got.shape, want.shape)
         assert torch.equal(got, want), (t, float((got - want).abs().max()))
 
+    if nbn == 1 or with_res:
+        # the same launches with the ReLU decision as ONE BIT per element (HtrvtGemmDesc.relu_bits; htrvt_bn_apply_mask writes
+        # it in the forward pass): bit (i & 7) of byte (i >> 3) over the flattened NHWC tensor -- identical output and sums
+        import numpy as np
+        mask = torch.from_numpy(np.packbits((relu_src > 0).numpy().reshape(-1), bitorder="little")).cuda()
+        parts_b = [torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nbn)]
+        out_b = eng.conv_dgrad(dyd, wd, geom, residual=res.to(dtype).cuda() if with_res else None, relu_src=mask, relu_bits=True,
+                               bnb=[(bnb[t][0], bnb[t][1], bnb[t][2], parts_b[t]) for t in range(nbn)])
+        assert torch.equal(out_b, out)
+        for t in range(nbn):
+            assert torch.equal(parts_b[t], parts[t]), t
+
 
 @pytest.mark.parametrize("ratio", [1.0, 60.0, 100.0])
 def test_conv_dgrad_fused_bn_sums_large_mean(ratio):

@@ -212,6 +212,25 @@ def main():
         conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
         conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
+    if "fdgrad" in args.only:      # the stride-1 conv dgrads with the fused backward epilogues of the stem (engine.backward): side inputs per element
+        for tag, (B, Hi, Wi, C) in (("l1 192", (128, 8, 1024, 192)), ("l2 384", (128, 4, 512, 384)), ("l3 768", (128, 2, 256, 768))):
+            g = ops.ConvGeom(B, Hi, Wi, C, C, 3, (1, 1), 1)
+            M = B * Hi * Wi
+            dy, wd, dx = rnd(B, Hi, Wi, C), rnd(C, g.taps, C), torch.empty(B, Hi, Wi, C, dtype=dt, device=dev)
+            x0, x1, res, act = rnd(B, Hi, Wi, C), rnd(B, Hi, Wi, C), rnd(B, Hi, Wi, C), rnd(B, Hi, Wi, C)
+            mean, rstd = torch.rand(C, device=dev) - 0.5, torch.rand(C, device=dev) + 0.5
+            sc, sf = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) - 0.5
+            nmt = ops.gemm_num_mtiles(M, C, dt, gather=ops.GATHER_CONV_DGRAD)
+            p0, p1 = (torch.empty(nmt, 2, C, dtype=torch.float32, device=dev) for _ in range(2))
+            fl = 2.0 * M * C * g.taps * C
+            kw = dict(dtype=dt, M=M, N=C, K=g.taps * C, lda=C, ldb=g.taps * C, ldc=C, gather=ops.GATHER_CONV_DGRAD, geom=g, Cpad=C)
+            rows.append((f"{tag} dgrad plain", timeit(lambda: ops.gemm(dy, wd, dx, **kw), args.iters), fl))
+            rows.append((f"{tag} dgrad relu-from-bn + 1 sum set", timeit(lambda: ops.gemm(dy, wd, dx, bnb=[(x0, mean, rstd, p0)], relu_bn=(sc, sf), **kw), args.iters), fl))
+            rows.append((f"{tag} dgrad res + relu + 1 sum set", timeit(lambda: ops.gemm(dy, wd, dx, residual=res, relu_src=act, bnb=[(x0, mean, rstd, p0)], **kw), args.iters), fl))
+            bits = torch.randint(0, 256, (M * C // 8,), dtype=torch.uint8, device=dev)
+            rows.append((f"{tag} dgrad res + relu BITS + 1 sum set", timeit(lambda: ops.gemm(dy, wd, dx, residual=res, relu_src=bits, relu_bits=True, bnb=[(x0, mean, rstd, p0)], **kw), args.iters), fl))
+            rows.append((f"{tag} dgrad res + relu BITS + 2 sum sets", timeit(lambda: ops.gemm(dy, wd, dx, residual=res, relu_src=bits, relu_bits=True, bnb=[(x0, mean, rstd, p0), (x1, mean, rstd, p1)], **kw), args.iters), fl))
+            rows.append((f"{tag} dgrad res + relu + 2 sum sets", timeit(lambda: ops.gemm(dy, wd, dx, residual=res, relu_src=act, bnb=[(x0, mean, rstd, p0), (x1, mean, rstd, p1)], **kw), args.iters), fl))
     for tag, ms, fl in rows:
         if isinstance(ms, dict):
             print(f"{tag:42s} " + "  ".join(f"{k}: {v:7.3f} ms {fl / v / 1e9:7.1f} TF" for k, v in ms.items()))

@@ -191,28 +191,58 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
     return __builtin_bit_cast(bf16x8_t, r);
   };
 
+  // ---- main loop, ONE barrier per k-tile, in the MIDDLE of it ----
+  // The barrier used to sit between k-tiles: every wave arrived with its last MFMAs issued, and all twelve then started the
+  // next k-tile by requesting fragments with nothing to multiply -- LDS latency plus the issue time of ~130 transposed reads per
+  // k-tile boundary with the matrix pipes idle (~10 % of a k-tile).  Now the barrier of k-tile t sits between its k-steps 1 and 2:
+  //   * before it a wave waits for ITS pieces of tile t + 1 (issued behind the barrier of tile t - 1: a whole k-tile ago), so
+  //     behind it tile t + 1 is complete -- the next k-tile starts without a barrier, in straight-line code that the compiler
+  //     software-pipelines like any two k-steps (the reads of (t + 1, step 0) sit between the MFMAs of (t, step 3));
+  //   * behind it every wave is past the first half of tile t, so nobody reads tile t - 1 any more: its stage takes the DMA
+  //     of tile t + 2;
+  //   * the fragments of step 2 are requested BEFORE the wait and the barrier: they are there when the barrier opens.
+  auto kstep_load = [&](const char* xs, const char* ys, int s, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = xfrag(xs, i, s);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, HTRVT_MNMAJOR>(ys, wn * TN + j, s, lane);
+  };
+  auto kstep_mma = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+  auto kstep = [&](const char* xs, const char* ys, int s) {
+    bf16x8_t fa[TM], fb[TN];
+    kstep_load(xs, ys, s, fa, fb);
+    kstep_mma(fa, fb);
+  };
+  bf16x8_t fa2[TM], fb2[TN];          // step 2 of the current k-tile, requested ahead of the barrier
+  if (nkt > 0) {                       // first half of tile 0 (landed: prologue barrier)
+    kstep(smem, smem + H::XBYTES, 0);
+    kstep(smem, smem + H::XBYTES, 1);
+    kstep_load(smem, smem + H::XBYTES, 2, fa2, fb2);
+  }
   int cur = 0, nxt = 2;
   for (int kt = 0; kt < nkt; ++kt) {
     const char* xs = smem + cur * H::STAGE;
     const char* ys = xs + H::XBYTES;
-    issue(nxt);            // k-tile kt + 2 (zero fill past the range): its stage was read in k-tile kt - 1
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = xfrag(xs, i, s);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, HTRVT_MNMAJOR>(ys, wn * TN + j, s, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    wait_one_tile_in_flight();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt + 1
     __builtin_amdgcn_s_barrier();
+    issue(nxt);            // k-tile kt + 2 (zero fill past the range) into the stage of tile kt - 1
+    kstep_mma(fa2, fb2);
+    kstep(xs, ys, 3);
     cur = cur == 2 ? 0 : cur + 1;
     nxt = nxt == 2 ? 0 : nxt + 1;
+    if (kt + 1 < nkt) {    // first half of the next tile: complete since the barrier above
+      const char* xn = smem + cur * H::STAGE;
+      const char* yn = xn + H::XBYTES;
+      kstep(xn, yn, 0);
+      kstep(xn, yn, 1);
+      kstep_load(xn, yn, 2, fa2, fb2);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -17,6 +17,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int RT = 32;                       // tile edge along Co and along Ci
 constexpr int MAXT = 9;                      // taps held in one LDS tile
+constexpr int LU = 4;                        // global loads a thread keeps in flight in the gather loops
 constexpr int SMEM_FLOATS = RT * (RT * MAXT + 1);
 static_assert(SMEM_FLOATS >= 64 * 65, "the Linear cast+transpose tile (64 x 65 floats) shares the buffer");
 
@@ -44,11 +45,24 @@ __device__ void pack_conv_tile(const HtrvtRelayoutJob& J, int tile, float* smem)
   T* fwd = static_cast<T*>(J.dst0);
   T* dgr = static_cast<T*>(J.dst1);
   const int lim = nci * taps;                                   // valid floats of one co row of the tile
-  for (int i = threadIdx.x; i < RT * run; i += NT) {
-    const int r = i / run, c = i - r * run;
-    float v = 0.f;
-    if (r < nco && c < lim) v = w[((long long)(co0 + r) * Ci + ci0) * taps + c];
-    smem[r * ldt + c] = v;
+  // loads from clamped, always-valid addresses and a select behind them, LU at a time: under `if (valid)` every load sat in its
+  // own branch with its own wait, one memory round trip per element and thread (36 per tile)
+  for (int i0 = threadIdx.x; i0 < RT * run; i0 += NT * LU) {
+    float v[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = i0 + u * NT;
+      const int r = i / run, c = i - r * run;
+      const bool ok = i < RT * run && r < nco && c < lim;
+      const float ld = w[ok ? ((long long)(co0 + r) * Ci + ci0) * taps + c : 0ll];
+      v[u] = ok ? ld : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = i0 + u * NT;
+      const int r = i / run, c = i - r * run;
+      if (i < RT * run) smem[r * ldt + c] = v[u];
+    }
   }
   __syncthreads();
   // pads (ci in Ci .. cpi-1, co in Co .. cpo-1) are never written: the buffers are zero-initialised by their owner; the odd
@@ -100,18 +114,42 @@ __device__ void unpack_wgrad_tile(const HtrvtRelayoutJob& J, int tile, float* sm
   const int nco = min(RT, Co - co0), nci = min(RT, Ci - ci0);
   const float* packed = static_cast<const float*>(J.src);
   float* grad = static_cast<float*>(J.dst0);
-  for (int i = threadIdx.x; i < RT * run; i += NT) {
-    const int ci = i / run, rem = i - ci * run;
-    const int t = rem / RT, r = rem - t * RT;
-    float v = 0.f;
-    if (ci < nci && r < nco) v = packed[((long long)t * cpi + ci0 + ci) * Co + co0 + r];
-    smem[r * ldt + ci * taps + t] = v;
+  for (int i0 = threadIdx.x; i0 < RT * run; i0 += NT * LU) {
+    float v[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = i0 + u * NT;
+      const int ci = i / run, rem = i - ci * run;
+      const int t = rem / RT, r = rem - t * RT;
+      const bool ok = i < RT * run && ci < nci && r < nco;
+      const float ld = packed[ok ? ((long long)t * cpi + ci0 + ci) * Co + co0 + r : 0ll];
+      v[u] = ok ? ld : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = i0 + u * NT;
+      const int ci = i / run, rem = i - ci * run;
+      const int t = rem / RT, r = rem - t * RT;
+      if (i < RT * run) smem[r * ldt + ci * taps + t] = v[u];
+    }
   }
   __syncthreads();
   const int lim = nci * taps;
-  for (int i = threadIdx.x; i < RT * run; i += NT) {
-    const int r = i / run, c = i - r * run;
-    if (r < nco && c < lim) grad[((long long)(co0 + r) * Ci + ci0) * taps + c] += smem[r * ldt + c];
+  for (int i0 = threadIdx.x; i0 < RT * run; i0 += NT * LU) {
+    float g[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {      // (element 0 is re-read by the masked lanes, never written by them)
+      const int i = i0 + u * NT;
+      const int r = i / run, c = i - r * run;
+      const bool ok = i < RT * run && r < nco && c < lim;
+      g[u] = grad[ok ? ((long long)(co0 + r) * Ci + ci0) * taps + c : 0ll];
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = i0 + u * NT;
+      const int r = i / run, c = i - r * run;
+      if (i < RT * run && r < nco && c < lim) grad[((long long)(co0 + r) * Ci + ci0) * taps + c] = g[u] + smem[r * ldt + c];
+    }
   }
 }
 
@@ -126,13 +164,24 @@ __device__ void cast_transpose_tile(const HtrvtRelayoutJob& J, int tile, float* 
   const float* src = static_cast<const float*>(J.src);
   T* dst = static_cast<T*>(J.dst0);
   T* dst_t = static_cast<T*>(J.dst1);
-  for (int rr = ty; rr < 64; rr += NT / 64) {
-    const int r = r0 + rr, c = c0 + tx;
-    const float v = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
-    smem[rr * 65 + tx] = v;
-    if (dst != nullptr && r < rows && c < cols) dst[(long long)r * cols + c] = from_f32<T>(v);
+  for (int rb = ty; rb < 64; rb += (NT / 64) * LU) {
+    float v[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int r = r0 + rb + u * (NT / 64), c = c0 + tx;
+      const bool ok = r < rows && c < cols;
+      const float ld = src[ok ? (long long)r * cols + c : 0ll];
+      v[u] = ok ? ld : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int rr = rb + u * (NT / 64), r = r0 + rr, c = c0 + tx;
+      smem[rr * 65 + tx] = v[u];
+      if (dst != nullptr && r < rows && c < cols) dst[(long long)r * cols + c] = from_f32<T>(v[u]);
+    }
   }
   __syncthreads();
+#pragma unroll 4
   for (int cc = ty; cc < 64; cc += NT / 64) {
     const int c = c0 + cc, r = r0 + tx;
     if (c < cols && r < ld_t) dst_t[(long long)c * ld_t + r] = from_f32<T>(smem[tx * 65 + cc]);   // rows >= `rows` were read as 0

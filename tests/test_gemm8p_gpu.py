@@ -114,7 +114,7 @@ def test_conv_dgrad_fused_epilogues(force_tile, tile, cfg, nbn, with_res):
     force_tile(tile)
     T.test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res)
     if tile == 11 and cfg[3] % 12 == 0:      # (tile 0 = the shipped route: convolutions on the loader-wave kernels)
-        assert "gemm8p_kernel" in _last_kernel(), _last_kernel()
+        assert "gemm8p_kernel" in T.LAST_FUSED_KERNEL, T.LAST_FUSED_KERNEL    # (the bit-mask launches behind it are staged-epilogue only)
 
 
 @pytest.mark.parametrize("tile", [10, 11])

@@ -260,6 +260,7 @@ def _sparse_ints(shape, seed, p=0.25):
     return (torch.randint(-1, 2, shape, generator=g) * (torch.rand(shape, generator=g) < p)).double()
 
 
+LAST_FUSED_KERNEL = ""
 FUSED_DGRAD = [  # B, Hi, Wi, Ci, Co, k, stride, pad
     (2, 8, 256, 192, 192, 3, (1, 1), 1),     # layer-1 body: 16 full M tiles
     (1, 5, 100, 192, 192, 3, (1, 1), 1),     # M = 500: tail tile
@@ -314,6 +315,9 @@ def test_conv_dgrad_fused_relu_bn_sums_exact(cfg, nbn, with_res):
 
     out = eng.conv_dgrad(dyd, wd, geom, residual=res.to(dtype).cuda() if with_res else None,
                          relu_src=relu_src.to(dtype).cuda(), bnb=bnb)
+    global LAST_FUSED_KERNEL        # which kernel served the launch above (tests/test_gemm8p_gpu.py forces families and checks)
+    from htrvt_amd._lib import lib as _l
+    LAST_FUSED_KERNEL = _l.htrvt_last_kernel().decode()
     assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
 
     # expected partial rows: 256-row M tiles of every launch, in launch order

@@ -149,7 +149,7 @@ def parity_path(args, dev, x, tg, tl, keep):
         model = build_model(args, cd).to(dev).train()
         tr = Trainer(model, max_lr=1e-3, weight_decay=0.5, world_size=1, use_collectives=False)
         steps = 3
-        for _ in range(3 if tag == "split_bf16" else 2):      # warm-up: the caching allocator's pool reaches its steady-state size by the third split step
+        for _ in range(3):      # warm-up: the caching allocator's pool reaches its steady-state size by the third split step (both legs: same step's loss)
             tr.step(x, tg, tl, keep_mask=keep)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -212,6 +212,21 @@ def main():
         conv("l1 192->192 s1 [128,8,1024]", 128, 8, 1024, 192, 192, 3, (1, 1), 1)
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
         conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
+    if "head" in args.only:        # the 80-class head (N = 80 padded to 80: float32 logits), forward / dgrad / weight gradient
+        M, D, C = 32768, 768, 80
+        a, w = rnd(M, D), rnd(C, D)
+        c32 = torch.empty(M, C, dtype=torch.float32, device=dev)
+        bias = torch.rand(C, device=dev)
+        rows.append(("head fwd 32768x80x768 f32 out", timeit(lambda: ops.gemm(a, w, c32, dtype=dt, M=M, N=C, K=D, lda=D, ldb=D, ldc=C, c_f32=True, bias=bias), args.iters), 2.0 * M * C * D))
+        cb = torch.empty(M, C, dtype=dt, device=dev)
+        rows.append(("head fwd 32768x80x768 bf16 out", timeit(lambda: ops.gemm(a, w, cb, dtype=dt, M=M, N=C, K=D, lda=D, ldb=D, ldc=C, bias=bias), args.iters), 2.0 * M * C * D))
+        plain("NT 32768x128x768", M, 128, D)
+        dyh, wt = rnd(M, C), rnd(D, C)
+        dx = torch.empty(M, D, dtype=dt, device=dev)
+        rows.append(("head dgrad 32768x768x80", timeit(lambda: ops.gemm(dyh, wt, dx, dtype=dt, M=M, N=D, K=C, lda=C, ldb=C, ldc=D), args.iters), 2.0 * M * C * D))
+        tn("TN head wgrad 80x768xK32768", C, D, M, 8)
+        tn("TN head wgrad^T 768x80xK32768", D, C, M, 8)
+        tn("TN head wgrad^T 768x80xK32768 split 28", D, C, M, 28)
     if "fdgrad" in args.only:      # the stride-1 conv dgrads with the fused backward epilogues of the stem (engine.backward): side inputs per element
         for tag, (B, Hi, Wi, C) in (("l1 192", (128, 8, 1024, 192)), ("l2 384", (128, 4, 512, 384)), ("l3 768", (128, 2, 256, 768))):
             g = ops.ConvGeom(B, Hi, Wi, C, C, 3, (1, 1), 1)

@@ -91,3 +91,88 @@ def test_trainer_collective_path_one_rank_nccl(dtype):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, dtype], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP1 OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+CHILD2 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")                      # two ranks share ONE GPU: RCCL refuses that, gloo moves the buckets through the host
+rank, world = dist.get_rank(), dist.get_world_size()
+from functools import partial
+import htrvt_amd
+from htrvt_amd.model import HTR_VT
+from htrvt_amd.trainer import Trainer
+from oracle import htrvt_oracle as O                 # synthetic inputs only (test infrastructure)
+
+D, L, h = 256, 4, 4
+cfg = O.Config(80, (64, 512), embed_dim=D, depth=L, num_heads=h)
+x, tg, tl = O.synthetic_batch(4, 64, 512, 80, cfg.num_patches, seed=11 + rank)      # every rank its own lines
+x = x.to(dev)
+
+
+def build(coll):
+    torch.manual_seed(123)
+    m = HTR_VT.MaskedAutoencoderViT(80, img_size=[64, 512], patch_size=(4, 64), embed_dim=D, depth=L, num_heads=h,
+                                    mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), compute_dtype=torch.float32)
+    m = m.to(dev).train()
+    return m, Trainer(m, max_lr=1e-3, weight_decay=0.5, world_size=world if coll else 1, use_collectives=coll)
+
+
+torch.manual_seed(7)
+m, tr = build(True)
+k1 = m.generate_span_mask(cfg.num_patches, 0.4, 8)
+k2 = m.generate_span_mask(cfg.num_patches, 0.4, 8)
+tr.step(x, tg, tl, keep_mask=k1)
+g_dp = tr.flat.flat_g.clone()
+tr.step(x, tg, tl, keep_mask=k1)
+tr.sam_step(x, tg, tl, keep_mask=k1, keep_mask2=k2)
+torch.cuda.synchronize()
+p_dp = tr.flat.flat_p.clone()
+
+# (1) the replicas stay in step: parameters after two AdamW steps and one SAM iteration are the same bits on both ranks
+both = [torch.empty_like(p_dp) for _ in range(world)]
+dist.all_gather(both, p_dp)
+assert torch.equal(both[0], both[1]), int((both[0] != both[1]).sum())
+assert torch.isfinite(p_dp).all()
+
+# (2) what was applied is the MEAN gradient: the same first step without collectives on this rank's lines, averaged by hand
+#     (1 / world is a power of two: scaling commutes with every rounding, so the comparison is bitwise)
+m2, tr2 = build(False)
+tr2.step(x, tg, tl, keep_mask=k1)
+g_loc = tr2.flat.flat_g.clone()
+dist.all_reduce(g_loc)
+g_loc *= 1.0 / world
+assert torch.equal(g_dp, g_loc), (int((g_dp != g_loc).sum()), float((g_dp - g_loc).abs().max()))
+assert float(g_dp.abs().sum()) > 0
+dist.barrier()
+dist.destroy_process_group()
+print("DP2 OK rank", rank)
+'''
+
+
+def test_trainer_two_ranks_on_one_gpu_gloo():
+    """WORLD_SIZE = 2 through the real kernels: two processes on the one GPU of the test box, gloo as the transport (RCCL
+    needs one device per rank).  Every rank trains on its own lines; the three bucketed all-reduces, the 1 / world gradient
+    scale and the waits between the compute, weight-gradient and collective streams must leave (1) bit-identical parameters
+    on both ranks after two AdamW steps and one SAM iteration and (2) exactly the mean of the two ranks' local gradients."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-c", CHILD2, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=600))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for rank, (pr, (so, se)) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and f"DP2 OK rank {rank}" in so, (rank, so[-2000:], se[-4000:])

@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--forward-only", action="store_true", help="config 2: eval forward + CTC loss only")
     ap.add_argument("--sam", action="store_true", help="the reference's full iteration (train.py:119-128): SAM(AdamW) = two "
                     "fwd+bwd passes + climb/restore + AdamW + ModelEma update; images/s counts each image once")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend. nccl (= RCCL) is the measured one; gloo lets N ranks SHARE one GPU (rank r uses "
+                         "device r %% device_count) to rehearse the N > 1 control flow of this script on a one-GPU box -- the "
+                         "numbers of such a run mean nothing")
     ap.add_argument("--rehearse-collectives", action="store_true", help="N = 1 under a launcher: run the RCCL gradient "
                     "all-reduces anyway (exercises the N > 1 code path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,6 +294,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.backend == "gloo":
+        local %= max(torch.cuda.device_count(), 1)      # rehearsal: the ranks share the devices that exist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # one rank needs no collective: under a launcher at N = 1 the process group is still created (the launcher's
@@ -298,7 +304,10 @@ def main():
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import htrvt_amd
     from htrvt_amd import ops
@@ -472,6 +481,8 @@ def main():
                           "graph_replay": args.graph != "off" and not (args.forward_only or args.sam),
                           "loss": float(loss.mean().item()) if loss is not None else None},
                "roofline": roof}
+        if world > 1:
+            out["config"]["collective_backend"] = "rccl" if args.backend == "nccl" else "gloo (ranks share a GPU: a rehearsal of the control flow, not a measurement)"
         if strong is not None:
             out["strong"] = strong
         if (not args.no_parity_path and world == 1 and args.dtype == "bf16" and not args.forward_only and not args.sam

@@ -176,3 +176,26 @@ def test_trainer_two_ranks_on_one_gpu_gloo():
                 pr.kill()
     for rank, (pr, (so, se)) in enumerate(zip(procs, outs)):
         assert pr.returncode == 0 and f"DP2 OK rank {rank}" in so, (rank, so[-2000:], se[-4000:])
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """`bench.py --gpus 2` end to end on the one GPU of the test box (`--backend gloo`: the ranks share the device): the
+    N > 1 branch of the script -- process group, per-rank data, barriers, max-over-ranks timing, the strong-scaling leg, the
+    two profiled steps on every rank, rank 0's ONE JSON line -- which the driver's 8-GPU run is the first to execute
+    otherwise.  The numbers of such a run mean nothing; the record's shape is what is checked."""
+    import json
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--width", "512", "--embed-dim", "256", "--depth", "4", "--heads", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert d["strong"]["global_batch"] == 8 and d["strong"]["batch_per_gpu"] == 4 and d["strong"]["value"] > 0
+    assert "gloo" in d["config"]["collective_backend"]

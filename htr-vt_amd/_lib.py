@@ -60,6 +60,7 @@ PROTOTYPES = {
     "htrvt_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "htrvt_gemm_num_mtiles": (i32, [C.POINTER(GemmDesc)]),
     "htrvt_gemm_wgrad_tiling": (i32, [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32)]),
+    "htrvt_gemm_dgrad_merged_tiles": (i32, [C.POINTER(GemmDesc)]),
     "htrvt_img_stats": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "htrvt_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "htrvt_stem_stats_rows": (i32, [i32, i32]),

@@ -402,12 +402,29 @@ extern "C" int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d) {
   return (d->M + bm - 1) / bm;
 }
 
+namespace htrvt {
+int gemm_halo_s2_try_launch(const HtrvtGemmDesc*, KParams&, hipStream_t, bool probe);
+}
+
+// number of M tiles (= rows of a fused BatchNorm-backward partial buffer) of the merged strided-dgrad launch `d`
+// (cls_h = cls_w = -2), or 0 when that form does not serve it and the caller launches one parity class at a time
+extern "C" int htrvt_gemm_dgrad_merged_tiles(const HtrvtGemmDesc* d) {
+  if (d == nullptr) return 0;
+  KParams p;
+  const int r = gemm_halo_s2_try_launch(d, p, nullptr, true);
+  return r > 0 ? r : 0;
+}
+
 static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int zdim, hipStream_t st);
 
 extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   HTRVT_REQUIRE(d != nullptr, "htrvt_gemm: null descriptor");
   HTRVT_REQUIRE(d->dtype == HTRVT_F32 || d->dtype == HTRVT_BF16, "htrvt_gemm: bad dtype %d", d->dtype);
   const bool cls = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0;
+  // cls_h == -2: every parity class of a strided dgrad in ONE launch (gemm_halo.hip: gemm_halo_s2_try_launch); M = all input
+  // pixels, K = (taps + 1 with A2) * Cpad
+  const bool merged = d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h == -2;
+  HTRVT_REQUIRE(d->cls_h >= -2 && (d->cls_h != -2 || merged), "htrvt_gemm: cls_h = %d", d->cls_h);
   HTRVT_REQUIRE(d->M > 0 && d->N > 0 && (d->K > 0 || (cls && d->K == 0)), "htrvt_gemm: empty problem M=%d N=%d K=%d", d->M,
                 d->N, d->K);
   HTRVT_REQUIRE(!cls || (d->dtype == HTRVT_BF16 && d->tile != 1 && d->cls_h < d->sh && d->cls_w >= 0 && d->cls_w < d->sw),
@@ -433,7 +450,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
       HTRVT_REQUIRE(d->M == d->nB * d->Ho * d->Wo && d->K == taps * d->Cpad && d->N == d->Co && d->Cpad >= d->Ci,
                     "htrvt_gemm: conv fwd extents inconsistent");
     if (d->gather == HTRVT_GATHER_CONV_DGRAD && !cls)
-      HTRVT_REQUIRE(d->M == d->nB * d->Hi * d->Wi && d->K == taps * d->Cpad && d->N == d->Ci && d->Cpad >= d->Co,
+      HTRVT_REQUIRE(d->M == d->nB * d->Hi * d->Wi && d->K == (taps + ((merged && d->A2 != nullptr) ? 1 : 0)) * d->Cpad && d->N == d->Ci && d->Cpad >= d->Co,
                     "htrvt_gemm: conv dgrad extents inconsistent");
     if (d->gather == HTRVT_GATHER_CONV_WGRAD)
       HTRVT_REQUIRE(d->K == d->nB * d->Ho * d->Wo && d->M == taps * d->Cpad && d->N == d->Co && d->Cpad >= d->Ci &&
@@ -493,7 +510,7 @@ extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   const bool fused_bwd = d->relu_src != nullptr || d->bnb_partial[0] != nullptr;
   p.cls_h = p.cls_w = -1;
   p.extra_off = 0;
-  HTRVT_REQUIRE(d->A2 == nullptr || cls, "htrvt_gemm: A2 needs a parity-class dgrad launch");
+  HTRVT_REQUIRE(d->A2 == nullptr || cls || merged, "htrvt_gemm: A2 needs a parity-class dgrad launch");
   p.Hq = d->Hi; p.Wq = d->Wi;
   p.ntapsel = d->kh * d->kw;
   for (int t = 0; t < 12; ++t) p.tapsel[t] = (unsigned char)t;
@@ -558,6 +575,7 @@ static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int z
     if (r != 0) return r < 0 ? r : 0;
   }
   HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");
+  HTRVT_REQUIRE(d->cls_h != -2, "htrvt_gemm: the merged strided dgrad (cls_h = -2) is served by the halo kernels only; ask htrvt_gemm_dgrad_merged_tiles first");
   // per-tile column sums: the caller sized `colstats` with htrvt_gemm_num_mtiles, i.e. for the 256-row tiles of the LDS-DMA
   // family; when that family declines the launch (an operand of 2 GiB or more) the 128-row tiles below would write twice as
   // many rows -- refuse instead of overrunning the buffer (the engine splits such a launch along the batch)

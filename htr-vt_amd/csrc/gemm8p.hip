@@ -63,6 +63,7 @@ bool gemm8p_serves(const HtrvtGemmDesc* d) {
   // 15-25 % slower there (tools/bench_gemm.py --only conv --tiles 4 10 11: layer-1 forward 969 vs 813 TFLOP/s)
   if (!((d->tile == 0 && d->gather == HTRVT_GATHER_NONE) || (d->tile >= 9 && d->tile <= 11) || (d->tile >= 13 && d->tile <= 15 && d->gather == HTRVT_GATHER_NONE))) return false;
   if (d->dtype != HTRVT_BF16 || d->M <= 128) return false;
+  if (d->cls_h == -2) return false;                       // merged strided dgrad: halo kernels only (gemm_halo.hip)
   if (gemm_small_m_prefers_bn128(d)) return false;      // few rows, narrow N: more, narrower tiles (gemm_dma.hip pick_bn)
   if (d->a_layout != HTRVT_KMAJOR || d->b_layout != HTRVT_KMAJOR) return false;
   if (d->gather != HTRVT_GATHER_NONE && d->gather != HTRVT_GATHER_CONV_FWD && d->gather != HTRVT_GATHER_CONV_DGRAD) return false;

@@ -1,5 +1,7 @@
 // gemm_dma.hip -- host-side selection of the bfloat16 LDS-DMA GEMM kernel variant (kernels: gemm_dma_impl.h,
 // instantiated per N-tile width in gemm_dma_bn*.hip).
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 using namespace htrvt;
@@ -12,6 +14,8 @@ int gemm_dma_dispatch_bn192(const HtrvtGemmDesc*, const KParams&, int, hipStream
 int gemm_dma_dispatch_bn256(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_halo_try_launch(const HtrvtGemmDesc*, const KParams&, int bn, hipStream_t);
 int gemm_hwgrad_try_launch(const HtrvtGemmDesc*, KParams&, int zdim, hipStream_t);
+int gemm_halo_s2_try_launch(const HtrvtGemmDesc*, KParams&, hipStream_t, bool probe);
+int conv1x1_try_launch(const HtrvtGemmDesc*, KParams&, hipStream_t);
 }  // namespace htrvt
 
 namespace {
@@ -79,6 +83,12 @@ int gemm_dma_num_mtiles(const HtrvtGemmDesc* d) {
 
 int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
   if (d->dtype != HTRVT_BF16 || d->M <= 128 || d->tile == 1 || !extents_ok(d)) return 0;
+  if (d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h == -2) return gemm_halo_s2_try_launch(d, p, st, false);   // all parity classes, one launch
+  if (d->gather == HTRVT_GATHER_CONV_FWD && d->kh == 1 && d->kw == 1) {   // strided 1x1 downsample convolutions: HBM-rate streaming kernel (conv1x1.hip)
+    static const bool off = getenv("HTRVT_NO_CONV1X1") != nullptr && getenv("HTRVT_NO_CONV1X1")[0] == '1';   // A/B runs on one box
+    const int r = off ? 0 : conv1x1_try_launch(d, p, st);
+    if (r != 0) return r;
+  }
   if (d->relu_src != nullptr || d->bnb_partial[0] != nullptr) {
     // served only by the staged epilogue with a fixed column group per wave (12 waves, 6/4/2 column groups)
     if (!use_loader_waves(d) || d->c_f32 || (d->ldc & 7) || (d->N & 7)) return 0;

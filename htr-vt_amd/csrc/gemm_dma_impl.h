@@ -298,18 +298,25 @@ __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w &
 
 // DGRAD: compile the backward-of-ReLU / BatchNorm-backward-sum path (conv-dgrad kernels only: it costs registers)
 // CSTATS: compile the per-column sum / sum-of-squares path (conv-forward kernels only: BatchNorm batch statistics)
-template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS, class P>   // CSTATS (conv forward) also enables colscale / ReLU-last
+// MF: the MFMA shape the accumulators come from.  32: acc[i][j][r] = C(32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), 32 j + (lane & 31)).
+// 16 (v_mfma_f32_16x16x32_bf16, four 16 x 16 tiles per 32 x 32 block): acc[i][j][4 (2 a + b) + r] = C(32 i + 16 a + 4 (lane >> 4) + r,
+// 32 j + 16 b + (lane & 15))
+template <int TN, int BN, int BM, int NW_TOTAL, bool DGRAD, bool CSTATS, class P, int MF = 32>   // CSTATS (conv forward) also enables colscale / ReLU-last
 __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P& p, long long coff, int m0, int n0,
-                                                int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active) {
+                                                int wm, int wn, int tile_m, int lane, int wave, char* smem, bool active,
+                                                const int rmul = 1) {
+  // rmul: C row of tile row r is m0 + rmul * r (the merged strided-dgrad kernel, gemm_halo_impl.h: an M tile is 256 pixels
+  // of ONE parity class of an image row, i.e. every sw-th pixel); the side inputs follow the same rows
   constexpr int CST = Stg<BM>::CST;
   constexpr int NWAVES = NW_TOTAL, NTH = NW_TOTAL * 64, NWM = BM / 64;
   // tiles wider than 192 columns are staged in two passes (the column-major staging image must fit the LDS)
   constexpr int PASSES = BN > 192 ? 2 : 1;
   constexpr int TNP = TN / PASSES, BNS = BN / PASSES;
   const int h = lane >> 5, cl = lane & 31;
-  float cs1[TN], cs2[TN];
+  float cs1[TN], cs2[TN];        // MF = 32: sums of column 32 j + cl over this lane's rows
+  float ds1[TN][2], ds2[TN][2];  // MF = 16: of columns 32 j + 16 b + (lane & 15)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = ds1[j][0] = ds1[j][1] = ds2[j][0] = ds2[j][1] = 0.f;
   constexpr int GROUPS = BNS / 32;            // groups of 4 chunks (32 columns) per row
   constexpr int ITEMS = (BM / 16) * GROUPS;   // wave-level items: 16 rows x 32 columns
   const int lr = lane & 15, lg = lane >> 4;
@@ -369,6 +376,35 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
       scalev[jp] = p.alpha * p.colscale[n < p.N ? n : 0];
     }
   }
+  if constexpr (MF == 16) {     // (no bias / colscale on this form: conv forward raw output and conv dgrad only)
+#pragma unroll
+    for (int jp = 0; jp < TNP; ++jp) {
+      const int j = pass * TNP + jp;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int ccol = (wn * TNP + jp) * 32 + 16 * b + (lane & 15);
+            const int crow = (wm * 2 + i) * 32 + 16 * a + 4 * (lane >> 4);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = acc[i][j][4 * (2 * a + b) + r];
+              if constexpr (CSTATS) {
+                ds1[j][b] += x;
+                ds2[j][b] += x * x;
+              }
+              v[r] = x * scalev[jp] + biasv[jp];
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(smem + ccol * CST + crow * 2) = o;
+          }
+    }
+  } else
 #pragma unroll
   for (int jp = 0; jp < TNP; ++jp) {
     const int j = pass * TNP + jp;
@@ -454,7 +490,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
         const int rbk = id / GROUPS, cg = id - rbk * GROUPS;
         const int half = (cg * 32) / (TNP * 32);
         const int nbc = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
-        const int m = m0 + rbk * 16 + lr;
+        const int m = m0 + rmul * (rbk * 16 + lr);
         const unsigned off = (m < p.M && nbc < p.N) ? (unsigned)m * ldc + (unsigned)nbc : 0u;
         const uint4 v = *reinterpret_cast<const uint4*>(bx0 + off);
         if (k < U) pbx0[k % U] = v;
@@ -475,7 +511,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
         const int rbk = idc / GROUPS, cg = idc - rbk * GROUPS;   // (FIXED_COLS: cg == wave % GROUPS for every item)
         const int half = (cg * 32) / (TNP * 32);    // which wave column (wn) staged this column group
         const int nbc = n0 + (half * TN + pass * TNP) * 32 + (cg * 32 - half * TNP * 32) + lg * 8;
-        int m = m0 + rbk * 16 + lr;
+        int m = m0 + rmul * (rbk * 16 + lr);
         ok[u] = live && m < p.M && nbc < p.N;
         if (cls) {  // class row -> input-pixel row of the NHWC gradient
           int b, hq, wq;
@@ -627,6 +663,21 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
   }  // pass
   if (CSTATS && p.colstats != nullptr) {
     float* red = reinterpret_cast<float*>(smem + BNS * CST);  // [NWM][BN][2], behind the staged tile
+    if constexpr (MF == 16) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float s1 = ds1[j][b], s2 = ds2[j][b];
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (lane < 16 && active) {
+            const int c = (wn * TN + j) * 32 + 16 * b + lane;
+            red[(wm * BN + c) * 2 + 0] = s1;
+            red[(wm * BN + c) * 2 + 1] = s2;
+          }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);

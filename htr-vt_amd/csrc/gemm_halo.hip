@@ -24,4 +24,34 @@ int gemm_halo_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipSt
   return 0;
 }
 
+
+// Merged strided dgrad (HtrvtGemmDesc.cls_h == -2): 1 launched, 0 not served, < 0 error.  Sets p.tiles_m / tiles_n / Hq / Wq.
+// `probe`: only answer (tiles_m, or 0) -- htrvt_gemm_dgrad_merged_tiles
+int gemm_halo_s2_try_launch(const HtrvtGemmDesc* d, KParams& p, hipStream_t st, bool probe) {
+  if (d->gather != HTRVT_GATHER_CONV_DGRAD || d->dtype != HTRVT_BF16 || d->cls_h != -2) return 0;
+  if (d->tile != 0 && d->tile != 4 && d->tile != 12) return 0;
+  if (d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || d->sh != 2 || (d->sw != 1 && d->sw != 2)) return 0;
+  if ((d->Hi & 1) || d->Wi % d->sw || d->Ho != d->Hi / 2 || d->Wo != d->Wi / d->sw || (d->Wo % 256) != 0) return 0;
+  if (d->batch > 1 || d->split_k > 1 || d->c_f32 || d->N != d->Ci || d->M != d->nB * d->Hi * d->Wi) return 0;
+  if (d->K != (9 + (d->A2 != nullptr ? 1 : 0)) * d->Cpad) return 0;
+  if ((d->ldc & 7) || (d->N & 7) || (d->Co & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;
+  if (d->colscale != nullptr || d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->relu_scale != nullptr) return 0;
+  const long long lim = (1ll << 31) - 64;
+  const long long abytes = (long long)d->nB * d->Ho * d->Wo * d->Co * 2;
+  if (abytes >= lim || (long long)d->N * d->ldb * 2 >= lim) return 0;
+  if (d->A2 != nullptr) {
+    const long long diff = (const char*)d->A2 - (const char*)d->A;
+    if (diff <= 0 || diff + abytes >= lim) return 0;
+  }
+  const int bn = d->N <= 128 ? 128 : 192;
+  p.Hq = d->Hi / 2;
+  p.Wq = d->Wi / d->sw;
+  p.tiles_m = 2 * d->sw * d->nB * p.Hq * (p.Wq / 256);
+  p.tiles_n = (d->N + bn - 1) / bn;
+  if (probe) return p.tiles_m;
+  p.cls_h = p.cls_w = -1;
+  p.extra_off = d->A2 != nullptr ? (unsigned)((const char*)d->A2 - (const char*)d->A) : 0u;
+  return bn == 192 ? launch_halo_s2<192>(p, st) : launch_halo_s2<128>(p, st);
+}
+
 }  // namespace htrvt

@@ -114,6 +114,40 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
 
   // consumer fragment addressing: A row = wm*64 + i*32 + (lane & 31) + shift
   const int arow = wm * 64 + (lane & 31), ah = lane >> 5;
+#ifdef HTRVT_EXP_M16
+  // v_mfma_f32_16x16x32_bf16: the wave's 64 x (32 TN) block as 4 x (2 TN) tiles of 16 x 16, k-steps of 32.  Operand lane map:
+  // row l & 15, k chunk 4 s + (l >> 4); the four 16 x 16 tiles of 32 x 32 block (i, j) live in acc[i][j] as registers 4 (2 a + b) + r
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x4_t a4[2 * TM][2 * TN];
+#pragma unroll
+  for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int arow16 = wm * 64 + (lane & 15), ag = lane >> 4;
+  auto compute = [&](const char* sa, const char* sb, int shift) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[2 * TM], fb[2 * TN];
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i) {
+        const int row = arow16 + i * 16 + shift;
+        const int chunk = 4 * s + ag;
+        fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa + row * 128 + ((chunk ^ Geo<BM>::swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) {
+        const int row = wn * TN * 32 + j * 16 + (lane & 15);
+        const int chunk = 4 * s + ag;
+        fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + row * 128 + ((chunk ^ Geo<BN>::swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+          a4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], a4[i][j], 0, 0, 0);
+    }
+  };
+#else
   auto compute = [&](const char* sa, const char* sb, int shift) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -133,6 +167,7 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
+#endif
 
   int gdy = 0, gcc = 0;           // group g
   for (int g = 0; g < NG; ++g) {
@@ -176,7 +211,266 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
   if (!consumer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile
   __builtin_amdgcn_s_barrier();
 
+#ifdef HTRVT_EXP_M16
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][4 * (2 * a + b) + r] = a4[2 * i + a][2 * j + b][r];
+  epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
+#else
   epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strided 3x3 pad-1 convolution, INPUT GRADIENT, all stride-parity classes in ONE launch on halo-staged tiles
+// (resnet18.py:26,59-63: conv1 of each stage's first block, stride (2,1) / (2,2), and its 1x1 downsample branch).
+//
+// dx[hi][wi] receives the taps (dy, dx) with (hi + 1 - dy) % 2 == 0 and (wi + 1 - dx) % sw == 0, i.e. a pixel of
+// parity class (a, b) = (hi & 1, wi % sw) contracts a fixed tap subset against dY pixels at FIXED offsets from its
+// coarse position (hq, wq) = (hi >> 1, wi / sw):
+//     a = 0: kernel row 1 <- dY row hq          a = 1: kernel row 0 <- dY row hq + 1, kernel row 2 <- dY row hq
+//     sw = 1:        kernel columns 0, 1, 2 <- dY columns wq + 1, wq, wq - 1
+//     sw = 2, b = 0: kernel column 1 <- wq      b = 1: kernel column 0 <- wq + 1, kernel column 2 <- wq
+// An M tile is 256 consecutive coarse pixels of one coarse row and ONE class: per (kernel row, 64-channel chunk) ONE
+// halo tile of dY (coarse pixels wq0 - 1 .. wq0 + 256) serves the class's 1-3 column taps, exactly as in the stride-1
+// kernel above -- the per-class launches of the generic gather kernel staged one 256 x 64 A tile per tap, every class
+// launch re-read dY, and the class rows were scattered by a per-row index remap.  Tiles of the classes of one coarse
+// row are neighbours in the grid (same XCD: dY rows are read once), the heavier classes first.
+// A2 (HtrvtGemmDesc.A2): the gradient of the block's 1x1 downsample conv output rides along as three more single-tap
+// groups of the class-(0, 0) tiles (source = A + extra_off, weight slot 9), as in the per-class form.
+// Groups have 1, 2 or 3 k-tiles; the next group's halo tile is issued during the current group's first k-tile(s) and
+// always BEFORE the B pieces of the group's last k-tile, so the counted wait of that k-tile covers it.
+// ---------------------------------------------------------------------------------------------
+template <int BN, class P>
+__device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x) {
+  using H = HaloGeo<BN>;
+  constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = block_x;
+  if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int n0 = tile_n * BN;
+  // tile_m -> (coarse row, class, segment): classes of one coarse row are neighbours, heaviest first
+  const int sw = p.sw, ncls = 2 * sw;
+  const int segs = p.Wq >> 8;                               // 256-pixel segments per coarse row (host: Wq % 256 == 0)
+  const int per_row = ncls * segs;
+  const int rowq = tile_m / per_row, rem = tile_m - rowq * per_row;
+  const int cidx = rem / segs, seg = rem - cidx * segs;
+  const int ca = 1 - cidx / sw;                             // row parity of this tile's pixels
+  const int cb = sw == 2 ? 1 - (cidx & 1) : 0;              // column parity (sw = 2)
+  const int bimg = rowq / p.Hq, hq = rowq - bimg * p.Hq;
+  const int wq0 = seg << 8;
+  const int Hh = p.Ho, Ww = p.Wo, Cs = p.Co;                // gathered tensor dY [B, Ho, Wo, Co]: Ho = Hq, Wo = Wq
+  // kernel rows / columns of this class, 2 bits per entry (wave-uniform scalars)
+  const int nrow = ca ? 2 : 1;
+  const int dyp = ca ? (0 | (2 << 2)) : 1;                  // kernel row of row slot r
+  const int dhp = ca ? (1 | (0 << 2)) : 0;                  // dY row = hq + dh
+  const int ncol = sw == 1 ? 3 : (cb ? 2 : 1);
+  const int dxp = sw == 1 ? (0 | (1 << 2) | (2 << 4)) : (cb ? (0 | (2 << 2)) : 1);   // kernel column of column slot j
+  const int shp = sw == 1 ? (2 | (1 << 2) | (0 << 4)) : (cb ? (2 | (1 << 2)) : 1);   // halo row shift of column slot j
+  const int NC = p.Cpad / BK;
+  const bool has_x = p.extra_off != 0 && ca == 0 && cb == 0;
+  const int nmain = nrow * NC;                              // groups of the 3x3 taps
+  const int ngroups = nmain + (has_x ? NC : 0);
+  const int xtap = p.kh * p.kw;                             // weight slot of the 1x1 downsample conv
+  const int kend = (xtap + 1) * p.Cpad;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool consumer = wave < NWC;
+  const int lw = (wave - NWC) & 3;
+  const int wm = (wave >> 1) & 3, wn = wave & 1;
+  if (!consumer) __builtin_amdgcn_s_setprio(3);
+
+  DmaLoader<BN, HTRVT_KMAJOR, 0, 4> lb;
+  lb.init(p, p.B, p.ldb, n0, p.N, lw, lane);
+  const unsigned long long ba = (unsigned long long)p.A;
+  const i32x4_t rsrcA = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
+  const int rho0 = lw * 8 + (lane >> 3);
+  const int cgA = (lane & 7) ^ Geo<BM>::swz(rho0);
+  const unsigned lane_off = (unsigned)((wq0 - 1 + rho0) * Cs + cgA * 8) * 2u;
+  const unsigned lds0 = lds_addr_of(smem);
+
+  // Row slots of this tile: slot s < nrow = a kernel row of the 3x3 (dY row hq + dh), slot nrow = the 1x1 downsample
+  // gradient (A2).  abase[s]: byte offset of (bimg, source row, pixel 0, channel 0) from p.A, OOB for a row outside dY.
+  unsigned abase0, abase1, abasex;
+  {
+    const int h0 = hq + (dhp & 3), h1 = hq + ((dhp >> 2) & 3);
+    abase0 = (unsigned)h0 < (unsigned)Hh ? (unsigned)(((bimg * Hh + h0) * Ww) * Cs) * 2u : OOB;
+    abase1 = (nrow > 1 && (unsigned)h1 < (unsigned)Hh) ? (unsigned)(((bimg * Hh + h1) * Ww) * Cs) * 2u : OOB;
+    abasex = has_x ? (unsigned)(((bimg * Hh + hq) * Ww) * Cs) * 2u + p.extra_off : OOB;
+  }
+  const int nslot = nrow + (has_x ? 1 : 0);
+  // byte offset of (slot as, chunk ac)'s first pixel row, OOB for a row outside dY / past the last group.  (Formed HERE, on
+  // plain values: inside a by-reference lambda hipcc turned the select over the three captured bases into a run-time
+  // index into the closure object, which then lived in scratch memory together with the DMA descriptors.)
+  auto group_base = [](int as, int ac, int nslot_, int nrow_, unsigned b0, unsigned b1, unsigned bx) -> unsigned {
+    const unsigned rb = as >= nslot_ ? OOB : (as == nrow_ ? bx : (as == 0 ? b0 : b1));
+    return rb < OOB ? rb + (unsigned)(ac * BK) * 2u : OOB;
+  };
+  // the halo tile at `gbase` (chunk ac) -> A stage `ast`, half `half`; gbase = OOB: zero fill
+  auto issueA = [&](int half, int ast, unsigned gbase, int ac) {
+    const bool chok = gbase < OOB && ac * BK + cgA * 8 < Cs;
+#pragma unroll
+    for (int i = 0; i < H::NP_AH; ++i) {
+      const int ii = half * H::NP_AH + i;
+      const int rho = rho0 + 32 * ii;
+      const int w = wq0 - 1 + rho;
+      const bool v = chok && rho < 258 && (unsigned)w < (unsigned)Ww;
+      const unsigned voff = v ? gbase + lane_off + (unsigned)(32 * ii * Cs) * 2u : OOB;
+      dma16(rsrcA, __builtin_amdgcn_readfirstlane(lds0 + ast * H::A_STAGE + (lw + 4 * ii) * 1024), voff);
+    }
+  };
+  // the k-tile sequence as the B loader walks it (two k-tiles ahead of the multiply): (slot, chunk, column slot)
+  int bs = 0, bc = 0, bj = 0;
+  auto issueB = [&](int bst) {
+    int k0 = kend;                                          // past the last k-tile: zero fill
+    if (bs < nslot) {
+      const bool x = bs == nrow;
+      const int tap = x ? xtap : ((dyp >> (2 * bs)) & 3) * 3 + ((dxp >> (2 * bj)) & 3);
+      k0 = tap * p.Cpad + bc * BK;
+      if (++bj == (x ? 1 : ncol)) {
+        bj = 0;
+        if (++bc == NC) {
+          bc = 0;
+          ++bs;
+        }
+      }
+    }
+    lb.template issue<true>(p, lds0 + H::B_BASE + bst * H::B_STAGE, k0, kend, lw);
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: halo tile of group 0, B of k-tiles 0 and 1 ----
+  if (!consumer) {
+    const unsigned gb0 = group_base(0, 0, nslot, nrow, abase0, abase1, abasex);
+    issueA(0, 0, gb0, 0);
+    issueA(1, 0, gb0, 0);
+    issueB(0);
+    issueB(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  const int arow = wm * 64 + (lane & 31), ah = lane >> 5;
+  auto compute = [&](const char* sa, const char* sb, int shift) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = arow + i * 32 + shift;
+        const int chunk = 2 * s + ah;
+        fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa + row * 128 + ((chunk ^ Geo<BM>::swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, HTRVT_KMAJOR>(sb, wn * TN + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  int bst = 0;                     // B stage of the k-tile being multiplied; the loaders fill (bst + 2) % 3
+  int gs = 0, gc = 0;              // (slot, chunk) of group g
+  for (int g = 0; g < ngroups; ++g) {
+    const int n = g < nmain ? ncol : 1;
+    int ns = gs, nc = gc + 1;      // group g + 1
+    if (nc == NC) {
+      nc = 0;
+      ++ns;
+    }
+    const unsigned ngb = group_base(ns, nc, nslot, nrow, abase0, abase1, abasex);
+    const char* sa = smem + (g & 1) * H::A_STAGE;
+    const int nast = (g + 1) & 1;
+    for (int j = 0; j < n; ++j) {
+      const bool last = j == n - 1;
+      const int fill = bst >= 1 ? bst - 1 : 2;          // (bst + 2) % 3
+      if (!consumer) {
+        if (n == 1) {             // both halves of the next halo tile, then B: the wait below covers the halo tile
+          issueA(0, nast, ngb, nc);
+          issueA(1, nast, ngb, nc);
+          issueB(fill);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+        } else if (n == 2) {      // k-tile 0: B + both halves (they have the group's second k-tile to land); k-tile 1: B
+          issueB(fill);
+          if (j == 0) {
+            issueA(0, nast, ngb, nc);
+            issueA(1, nast, ngb, nc);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B + 2 * H::NP_AH) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+          }
+        } else {                  // three k-tiles: the schedule of the stride-1 kernel
+          issueB(fill);
+          if (!last) {
+            issueA(j, nast, ngb, nc);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B + H::NP_AH) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+          }
+        }
+      } else {
+        const int shift = g < nmain ? (shp >> (2 * j)) & 3 : 1;
+        compute(sa, smem + H::B_BASE + bst * H::B_STAGE, shift);
+      }
+      __builtin_amdgcn_s_barrier();
+      bst = bst == 2 ? 0 : bst + 1;
+    }
+    gs = ns;
+    gc = nc;
+  }
+  if (!consumer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile
+  __builtin_amdgcn_s_barrier();
+
+  // C rows: pixel (bimg, 2 hq + ca, sw (wq0 + r) + cb) of the NHWC gradient, r = 0 .. 255
+  const int m0 = (bimg * p.Hi + 2 * hq + ca) * p.Wi + sw * wq0 + cb;
+  epilogue_staged<TN, BN, BM, NW_TOTAL, true, false>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer, sw);
+}
+
+template <int BN>
+__global__ __launch_bounds__(768) void gemm_halo_s2_kernel(const KParams p) {
+  typedef const __attribute__((address_space(4))) KParams KP;
+  (void)p;
+  KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+  gemm_halo_s2_body<BN>(*kp, (int)blockIdx.x);
+}
+
+template <int BN>
+int launch_halo_s2(const KParams& p, hipStream_t st) {
+  using H = HaloGeo<BN>;
+  static bool attr_done = false;
+  auto kern = gemm_halo_s2_kernel<BN>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(%d B LDS): %s", H::LDS_BYTES, hipGetErrorString(e));
+      return -2;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), H::LDS_BYTES, st, p);
+  set_last_kernel("gemm_halo_s2_kernel<%d>", BN);
+  const int rc = check_launch("gemm_halo_s2_kernel");
+  return rc ? rc : 1;
 }
 
 template <int BN, bool DGRAD>

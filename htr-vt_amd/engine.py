@@ -117,6 +117,9 @@ class Engine:
         # plus a residual round trip of the whole input gradient
         self.fuse_downsample_dgrad = True
         self.halo_wgrad = True         # 3x3 stride-1 conv weight gradients on the halo-staged kernel (csrc/gemm_hwgrad_impl.h)
+        # strided 3x3 conv dgrad: all parity classes in ONE launch on halo-staged tiles (csrc/gemm_halo_impl.h,
+        # gemm_halo_s2_kernel) instead of one gather launch per class
+        self.merged_strided_dgrad = True
         # split-K weight gradients through per-K-range slabs + an ordered sum instead of float atomics: bitwise reproducible
         # run to run (tests/test_determinism_gpu.py).  Round 3: also the bf16 default -- equal to the atomic form at 64-128
         # images per GPU (36.39 vs 36.41 ms), faster below (B = 32: 11.33 vs 11.48 ms, B = 16: 7.22 vs 7.57 ms: float atomics
@@ -402,7 +405,9 @@ class Engine:
         flops = 2.0 * Mo * No * Kred
         best, best_t = 1, None
         # multiples of 8 let the kernel keep all tiles of one K range on one XCD (shared L2); small factors otherwise
-        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, 129, 8)) + ([10, 12, 14, 20, 28] if tiling is not None else []):
+        # a single output tile (the 1x1 downsample weight gradients, K = 1 M pixels at layer 1): up to one K range per CU
+        smax = 257 if tiles == 1 else 129
+        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, smax, 8)) + ([10, 12, 14, 20, 28] if tiling is not None else []):
             if Kred // s < 512:
                 continue
             blocks = tiles * s
@@ -519,8 +524,32 @@ class Engine:
              gather=GATHER_CONV_FWD, geom=g, Cpad=cpi, colstats=cs, **kw)
         return y, cs, rows
 
+    def _dgrad_merged(self, g, dy=None, wd=None, dx=None, extra=None):
+        """M tiles of the merged strided-dgrad launch (HtrvtGemmDesc.cls_h = -2) when the library serves `g` in that form
+        (asked of the library itself: htrvt_gemm_dgrad_merged_tiles), else 0"""
+        if not (self.merged_strided_dgrad and self.gdt == torch.bfloat16 and not self.split and self._dgrad_by_class(g) and g.kh == 3):
+            return 0
+        import ctypes
+        from ._lib import GemmDesc
+        d = GemmDesc()
+        cpo = cpad(g.Co, self.dtype)
+        d.dtype, d.a_layout, d.b_layout, d.gather = dt(self.dtype), KMAJOR, KMAJOR, GATHER_CONV_DGRAD
+        d.M, d.N, d.K = g.B * g.Hi * g.Wi, g.Ci, (g.taps + (1 if extra is not None else 0)) * cpo
+        d.lda, d.ldb, d.ldc = g.Co, (g.taps + (1 if extra is not None else 0)) * cpo, g.Ci
+        g.fill(d)
+        d.Cpad, d.batch, d.split_k, d.cls_h, d.cls_w = cpo, 1, 1, -2, -2
+        # the pointer tests of the eligibility check (alignment, A2 behind A): the real ones when known, aligned stand-ins else
+        d.A = ptr(dy) if dy is not None else 4096
+        d.B = ptr(wd) if wd is not None else 4096
+        d.C = ptr(dx) if dx is not None else 4096
+        d.A2 = ptr(extra)
+        return int(lib.htrvt_gemm_dgrad_merged_tiles(ctypes.byref(d)))
+
     def dgrad_tiles(self, g: ConvGeom):
         """number of M tiles (rows of a fused BN-backward partial buffer) conv_dgrad will produce"""
+        nm = self._dgrad_merged(g)
+        if nm > 0:
+            return nm
         if self._dgrad_by_class(g):
             return sum(ops.gemm_num_mtiles(g.B * ((g.Hi - a + g.sh - 1) // g.sh) * ((g.Wi - b + g.sw - 1) // g.sw), g.Ci,
                                            self.dtype, gather=GATHER_CONV_DGRAD) for a in range(g.sh) for b in range(g.sw))
@@ -563,6 +592,12 @@ class Engine:
                     parts[(a, b)] = part
             check(lib.htrvt_class_scatter_f32(ptr(parts[(0, 0)]), ptr(parts.get((0, 1))), ptr(parts.get((1, 0))), ptr(parts.get((1, 1))),
                                               ptr(residual), ptr(dx), g.B, g.Hi, g.Wi, g.Ci, g.sh, g.sw, stream()), "class_scatter_f32")
+            return dx
+        if self._dgrad_merged(g, dy, wd, dx, extra) > 0:
+            # strided 3x3 conv: every parity class in one launch, halo-staged tiles; the downsample gradient rides along (A2)
+            gemm(dy, wd, dx, dtype=self.dtype, M=g.B * g.Hi * g.Wi, N=g.Ci, K=wtaps * cpo, lda=g.Co, ldb=wtaps * cpo, ldc=g.Ci,
+                 gather=GATHER_CONV_DGRAD, geom=g, Cpad=cpo, residual=residual, cls=(-2, -2), relu_src=relu_src,
+                 relu_bits=relu_bits, bnb=bnb, a2=extra)
             return dx
         if self._dgrad_by_class(g):
             # strided conv: one launch per input-pixel parity class, each contracting only the taps that reach it

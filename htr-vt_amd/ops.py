@@ -119,6 +119,8 @@ def gemm(A, B, Cout, *, dtype, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout
     e1.record()
     if geom is None:
         flops = 2.0 * M * N * K * max(batch, 1)
+    elif cls is not None and cls[0] == -2:   # every parity class in one launch: the convolution's MACs (+ the 1x1 downsample's with A2)
+        flops = 2.0 * geom.B * geom.Ho * geom.Wo * geom.Co * (K // Cpad) * geom.Ci
     elif cls is not None:   # one parity class of a strided dgrad: only its useful MACs
         flops = 2.0 * M * N * (K // Cpad) * geom.Co
     else:   # algorithmic FLOPs of the convolution, whichever of fwd/dgrad/wgrad this launch is

@@ -65,7 +65,12 @@ typedef struct HtrvtGemmDesc {
   int32_t nB, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, Cpad;
   /* HTRVT_GATHER_CONV_DGRAD of a strided conv, one launch per input-pixel parity class (bfloat16 only):
    * cls_h/cls_w in [0,sh)/[0,sw) select the pixels hi%sh==cls_h, wi%sw==cls_w (M = their count, row-major over
-   * (b, hi/sh, wi/sw)); K = (#taps that can reach this class) * Cpad (may be 0).  cls_h = -1: all pixels/taps. */
+   * (b, hi/sh, wi/sw)); K = (#taps that can reach this class) * Cpad (may be 0).  cls_h = -1: all pixels/taps.
+   * cls_h = cls_w = -2: ALL parity classes of a 3x3 pad-1 stride-(2,1) / (2,2) convolution in ONE launch on halo-staged
+   * tiles (csrc/gemm_halo_impl.h: gemm_halo_s2_kernel; resnet18.py:26 with stride from :59-63): M = nB*Hi*Wi, K = 9 * Cpad
+   * (10 * Cpad with A2, which then rides with the class-(0,0) tiles), the epilogue / side inputs address C rows as NHWC
+   * pixels, bnb_partial gets one row per (class, 256-pixel segment) tile in grid order.  Served only where
+   * htrvt_gemm_dgrad_merged_tiles() says so (Hi even, Wo a multiple of 256, operands inside 2 GiB). */
   int32_t cls_h, cls_w;
   /* Parity-class dgrad of class (0, 0) only, or NULL: A2 = the gradient of the block's 1x1 downsample convolution output
    * (resnet18.py:59-63: same stride, padding 0, same [B,Ho,Wo,Co] shape as A, allocated BEHIND A within 2 GiB).  Its
@@ -121,6 +126,9 @@ int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d);
  * Cpad a multiple of 64, float32 output, operands inside 2 GiB) serves the descriptor, 0 when the generic kernels do: the
  * caller's split-K choice must count the workgroups of the kernel that actually runs. */
 int htrvt_gemm_wgrad_tiling(const HtrvtGemmDesc* d, int* tile_rows, int* tile_cols);
+/* Merged strided dgrad (cls_h = cls_w = -2 above): the number of M tiles (= rows every bnb_partial buffer needs) when
+ * htrvt_gemm serves the descriptor in that form, 0 when the caller has to launch one parity class at a time. */
+int htrvt_gemm_dgrad_merged_tiles(const HtrvtGemmDesc* d);
 
 /* ---- stem helpers (resnet18.py:42-84, HTR_VT.py:134-136,224-227) ------------- */
 /* per-image mean / rstd of the raw image (param-free LayerNorm, eps 1e-5): stats[b] = {mean, rstd}.

@@ -142,6 +142,11 @@ CONVS = [  # B, Hi, Wi, Ci, Co, k, stride, pad
     (2, 8, 128, 64, 128, 3, (2, 2), 1),
     (3, 4, 64, 96, 192, 1, (2, 2), 0),
     (1, 2, 256, 192, 192, 3, (1, 1), 1),
+    # strided 1x1 downsample convolutions on the streaming kernel (csrc/conv1x1.hip): K = 192 / 384 / padded 96 -> 128, an M tail
+    (2, 16, 256, 192, 192, 1, (2, 1), 0),
+    (1, 6, 128, 192, 384, 1, (2, 2), 0),
+    (2, 4, 256, 96, 192, 1, (2, 2), 0),
+    (3, 4, 128, 384, 768, 1, (2, 2), 0),
 ]
 
 
@@ -166,6 +171,9 @@ def test_conv_fwd_dgrad_wgrad_exact(dtype, cfg):
     ops.gemm(xd, wf, yd, dtype=dtype, M=M, N=Co, K=geom.taps * cpi, lda=Ci, ldb=geom.taps * cpi, ldc=Co,
              gather=ops.GATHER_CONV_FWD, geom=geom, Cpad=cpi, colstats=cs)
     y_nhwc = y.detach().permute(0, 2, 3, 1)
+    if dtype == torch.bfloat16 and k == 1 and geom.Wo % (64 if cpi <= 192 else 32) == 0 and not getattr(ops, "_ENV_TILE", 0):
+        from htrvt_amd._lib import lib as _l
+        assert "conv1x1_fwd_kernel" in _l.htrvt_last_kernel().decode()
     assert torch.equal(yd.double().cpu(), y_nhwc.to(dtype).double())
     assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
     assert torch.allclose(cs[:, 1].sum(0).double().cpu(), (y_nhwc.reshape(-1, Co) ** 2).sum(0), rtol=1e-6, atol=1e-3)
@@ -389,3 +397,89 @@ def test_conv_dgrad_fused_bn_sums_large_mean(ratio):
     err = ((got - want).abs() / scale).max().item()
     print(f"mean / std = {ratio}: worst |sum g xhat error| / sum |g xhat| = {err:.2e}")
     assert err < 1e-3, err
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# strided 3x3 conv dgrad, every parity class in ONE launch on halo-staged tiles (HtrvtGemmDesc.cls_h = -2,
+# csrc/gemm_halo_impl.h gemm_halo_s2_kernel): plain, with the 1x1 downsample gradient as A2, and with the fused epilogue
+# --------------------------------------------------------------------------------------------------------------------
+MERGED_DGRAD = [  # B, Hi, Wi, Ci, Co, stride
+    (2, 16, 256, 192, 192, (2, 1)),     # layer1.0.conv1: 2 classes, three column taps per kernel row
+    (2, 8, 512, 192, 384, (2, 2)),      # layer2.0.conv1: 4 classes, groups of 1 and 2 k-tiles
+    (1, 4, 512, 384, 768, (2, 2)),      # layer3.0.conv1: two N tiles, dY rows hq + 1 past the image
+    (1, 2, 512, 64, 128, (2, 2)),       # one coarse row: every dh = +1 row is outside; 128-column tile
+]
+
+
+@pytest.mark.parametrize("cfg", MERGED_DGRAD)
+@pytest.mark.parametrize("with_a2", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])      # 0: plain; 1: ReLU bit mask + one sum set; 2: residual + ReLU source + two sum sets
+def test_conv_dgrad_merged_classes_exact(cfg, with_a2, fused):
+    import numpy as np
+    import htrvt_amd  # noqa: F401
+    from htrvt_amd.engine import Engine, ModelShape
+    from htrvt_amd._lib import lib as _l
+    ops = _ops()
+    dtype = torch.bfloat16
+    Bn, Hi, Wi, Ci, Co, stride = cfg
+    eng = Engine(ModelShape(80, (64, 512), 64, 2, 2), dtype, "cuda")
+    geom = ops.ConvGeom(Bn, Hi, Wi, Ci, Co, 3, stride, 1)
+    assert eng._dgrad_merged(geom) > 0
+    w = _sparse_ints((Co, Ci, 3, 3), 60)
+    wds = _sparse_ints((Co, Ci, 1, 1), 61)
+    dy = _sparse_ints((Bn, Co, geom.Ho, geom.Wo), 62)
+    dy2 = _sparse_ints((Bn, Co, geom.Ho, geom.Wo), 63)
+    dx = torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), w, dy, stride=stride, padding=1)
+    if with_a2:
+        dx = dx + torch.nn.grad.conv2d_input((Bn, Ci, Hi, Wi), wds, dy2, stride=stride, padding=0)
+    dx = dx.permute(0, 2, 3, 1)       # NHWC
+    cpo = ops.cpad(Co, dtype)
+    pair = torch.empty(2, Bn, geom.Ho, geom.Wo, Co, dtype=dtype, device="cuda")       # A2 lies behind A
+    pair[0].copy_(dy.permute(0, 2, 3, 1).to(dtype))
+    pair[1].copy_(dy2.permute(0, 2, 3, 1).to(dtype))
+    if with_a2:
+        wd = torch.zeros(Ci, 10, cpo, dtype=dtype)
+        wd[:, :9] = _pack_dgrad(w, cpo).to(dtype)
+        wd[:, 9:] = _pack_dgrad(wds, cpo).to(dtype)
+        wd = wd.cuda()
+    else:
+        wd = _pack_dgrad(w, cpo).to(dtype).cuda()
+    res = _ints((Bn, Hi, Wi, Ci), -3, 4, seed=64)
+    relu_src = _ints((Bn, Hi, Wi, Ci), -1, 2, seed=65)
+    kw, g_ref, nbn = {}, dx, 0
+    rows = eng.dgrad_tiles(geom)
+    if fused:
+        nbn = fused
+        g_ref = (dx + (res if fused == 2 else 0.0)) * (relu_src > 0)
+        gen = torch.Generator().manual_seed(66)
+        bnx = [_ints((Bn, Hi, Wi, Ci), -4, 5, seed=67 + t) for t in range(nbn)]
+        mean = [torch.randint(-2, 3, (Ci,), generator=gen).double() for _ in range(nbn)]
+        rstd = [torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (Ci,), generator=gen)].double() for _ in range(nbn)]
+        parts = [torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nbn)]
+        kw["bnb"] = [(bnx[t].to(dtype).cuda(), mean[t].float().cuda(), rstd[t].float().cuda(), parts[t]) for t in range(nbn)]
+        if fused == 1:
+            kw.update(relu_src=torch.from_numpy(np.packbits((relu_src > 0).numpy().reshape(-1), bitorder="little")).cuda(), relu_bits=True)
+        else:
+            kw.update(relu_src=relu_src.to(dtype).cuda(), residual=res.to(dtype).cuda())
+    assert g_ref.abs().max() < 256
+    out = eng.conv_dgrad(pair[0], wd, geom, extra=pair[1] if with_a2 else None, **kw)
+    assert "gemm_halo_s2_kernel" in _l.htrvt_last_kernel().decode()
+    assert torch.equal(out.double().cpu(), g_ref), float((out.double().cpu() - g_ref).abs().max())
+    if fused:
+        # partial rows in grid order: coarse row (b, hq) -> classes, heaviest first ((1,1), (1,0), (0,1), (0,0) / (1), (0)) -> segments
+        sh, sw = stride
+        classes = [(1 - c // sw, (1 - (c & 1)) if sw == 2 else 0) for c in range(2 * sw)]
+        for t in range(nbn):
+            xhat = (bnx[t] - mean[t]) * rstd[t]
+            want = []
+            for b in range(Bn):
+                for hq in range(Hi // 2):
+                    for (a, cb) in classes:
+                        for seg in range(Wi // sw // 256):
+                            sl = slice(sw * 256 * seg + cb, sw * 256 * (seg + 1), sw)
+                            gg, xx = g_ref[b, 2 * hq + a, sl, :], xhat[b, 2 * hq + a, sl, :]
+                            want.append(torch.stack([gg.sum(0), (gg * xx).sum(0)]))
+            want = torch.stack(want)
+            got = parts[t].double().cpu()
+            assert got.shape == want.shape, (got.shape, want.shape)
+            assert torch.equal(got, want), (t, float((got - want).abs().max()))

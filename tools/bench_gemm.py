@@ -231,6 +231,30 @@ def main():
         tn("TN head wgrad 80x768xK32768", C, D, M, 8)
         tn("TN head wgrad^T 768x80xK32768", D, C, M, 8)
         tn("TN head wgrad^T 768x80xK32768 split 28", D, C, M, 28)
+    if "sdgrad" in args.only:      # the three strided 3x3 conv dgrads of the stem as engine.backward launches them: per parity class vs merged
+        from htrvt_amd.engine import Engine, ModelShape
+        eng = Engine(ModelShape(80, (64, 1024), 768, 4, 6), dt)
+        for tag, (B, Hi, Wi, Ci, Co, st_), fused in (("l1.0 192->192 s(2,1)", (128, 16, 1024, 192, 192, (2, 1)), False),
+                                                      ("l2.0 192->384 s(2,2)", (128, 8, 1024, 192, 384, (2, 2)), True),
+                                                      ("l3.0 384->768 s(2,2)", (128, 4, 512, 384, 768, (2, 2)), True)):
+            g = ops.ConvGeom(B, Hi, Wi, Ci, Co, 3, st_, 1)
+            pair = rnd(2, B, g.Ho, g.Wo, Co)
+            wd = rnd(Ci, 10, Co)
+            fl = 2.0 * B * g.Ho * g.Wo * Co * 10 * Ci
+            x0 = rnd(B, Hi, Wi, Ci)
+            mean, rstd = torch.rand(Ci, device=dev) - 0.5, torch.rand(Ci, device=dev) + 0.5
+            bits = torch.randint(0, 256, (B * Hi * Wi * Ci // 8,), dtype=torch.uint8, device=dev)
+            res = {}
+            for rnd_ in range(args.rounds):
+                for mode in (False, True):
+                    eng.merged_strided_dgrad = mode
+                    rows_ = eng.dgrad_tiles(g)
+                    p0 = torch.empty(rows_, 2, Ci, dtype=torch.float32, device=dev)
+                    kw = dict(relu_src=bits, relu_bits=True, bnb=[(x0, mean, rstd, p0)]) if fused else {}
+                    t = _timeit(lambda: eng.conv_dgrad(pair[0], wd, g, extra=pair[1], **kw), args.iters)
+                    k = "merged" if mode else "per-class"
+                    res[k] = min(res.get(k, 1e9), t)
+            rows.append((tag + (" dgrad+A2 fused(bits+1set)" if fused else " dgrad+A2 plain"), res, fl))
     if "fdgrad" in args.only:      # the stride-1 conv dgrads with the fused backward epilogues of the stem (engine.backward): side inputs per element
         for tag, (B, Hi, Wi, C) in (("l1 192", (128, 8, 1024, 192)), ("l2 384", (128, 4, 512, 384)), ("l3 768", (128, 2, 256, 768))):
             g = ops.ConvGeom(B, Hi, Wi, C, C, 3, (1, 1), 1)

@@ -153,8 +153,11 @@ int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t 
     // auto: the plain / bias epilogue only.  With the GELU epilogue the folded flush is VALU-bound -- one wave per SIMD
     // evaluates erf while its partner's 16 MFMAs are long done -- and measured 2-3 % SLOWER than the unfolded epilogue, in
     // which both waves of a SIMD share the VALU (tools/bench_gemm.py --only enc --tiles 9 0: fc1 forward 830 vs 808 TFLOP/s)
-    const bool want = (d->tile >= 13 && d->tile <= 15) || (d->tile == 0 && !off && epi == 0);
-    if (want && (epi == 0 || epi == E_GELU) && zdim == 1 && d->batch <= 1 && d->K % 128 == 0 && d->K >= 256 &&
+    // round 5: bias + residual too (192-column tiles: proj / fc2 forward), the residual through registers (gemm8pp_impl.h)
+    static const bool res_off = getenv("HTRVT_NO_PERSISTENT_RES") != nullptr && getenv("HTRVT_NO_PERSISTENT_RES")[0] == '1';
+    const bool res_ok = epi == E_RES && bn == 192 && !res_off && d->K >= 256 && (reinterpret_cast<unsigned long long>(d->residual) & 3) == 0;
+    const bool want = (d->tile >= 13 && d->tile <= 15) || (d->tile == 0 && !off && (epi == 0 || res_ok));
+    if (want && (epi == 0 || epi == E_GELU || res_ok) && zdim == 1 && d->batch <= 1 && d->K % 128 == 0 && d->K >= 256 &&
         (reinterpret_cast<unsigned long long>(d->bias) & 15) == 0 && (d->preact == nullptr || (reinterpret_cast<unsigned long long>(d->preact) & 15) == 0)) {
       static int ncu = 0;
       if (ncu == 0) {

@@ -20,8 +20,17 @@
 //  * the only counted wait stays `s_waitcnt vmcnt(6)` per k-tile; in the flush k-tile it is vmcnt(6 + 4 NQ), NQ = the
 //    store instructions of one quadrant flush (they are issued between the DMA pieces and may stay outstanding).
 //
-// Epilogues served: bias (+ exact-erf GELU with the saved pre-activation).  Residual / GELU' need a side INPUT per
-// element; they stay on gemm8p_kernel.
+// Epilogues served: bias (+ exact-erf GELU with the saved pre-activation), and (round 5) bias + RESIDUAL.  A side input
+// per element must never be waited for in a way that drains the in-order vmcnt queue (loads, stores and LDS-DMA count
+// together).  The residual of a tile therefore arrives in REGISTERS through inline-asm buffer loads the compiler does
+// not see (it would put its own, too strict, waits in front of their uses) -- struct Side below:
+//   quadrants 0 and 1 of tile t are requested at the START of tile t's LAST k-tile -- older than that k-tile's eight DMA
+//   pieces, so the k-tile's own `vmcnt(6)` retires them: no extra wait;
+//   quadrants 2 and 3 are requested into the same registers right behind the flushes of quadrants 0 and 1 (phases 1, 2
+//   of the next tile's first k-tile) and awaited two phases later with COUNTED waits (vmcnt(4 + NQ + NL), vmcnt(2 + NQ))
+//   that leave every younger DMA piece and store in flight.
+// All four quadrants at once would need 48 more registers than the 256 a two-waves-per-SIMD kernel has.  GELU' (a side
+// input as well) stays on gemm8p_kernel.
 #pragma once
 #include "gemm8p_impl.h"
 
@@ -129,15 +138,80 @@ struct PLoadB {
   }
 };
 
+// The residual of two quadrants in flight / in use (E_RES): q[slot][i] = columns 0-7, q2[slot][i] = columns 8-11 (CW = 12) of row
+// tile i.  ON = false: no state, no code (the other epilogues compile exactly as before).
+template <class C, bool ON>
+struct Side {
+  __device__ __forceinline__ void init(const void*) {}
+  template <int SL, int X, int Y>
+  __device__ __forceinline__ void load(int, int, int, int, unsigned, int, int, int, int, int) {}
+  template <int SL, int CNT>
+  __device__ __forceinline__ void wait() {}
+  template <int SL>
+  __device__ __forceinline__ void add(int, float*) {}
+};
+template <class C>
+struct Side<C, true> {
+  static constexpr int MT = C::MT, CW = 4 * C::NT;
+  typedef int i32x2_t __attribute__((ext_vector_type(2)));
+  i32x4_t q[2][MT];
+  i32x2_t q2[2][MT];
+  i32x4_t rsrc;
+  __device__ __forceinline__ void init(const void* residual) {
+    const unsigned long long ba = (unsigned long long)residual;
+    rsrc = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), residual != nullptr ? (int)OOB : 0, 0x00020000};
+  }
+  // request quadrant (X, Y) of the tile at (tm0, tn0) into slot SL: inline asm, invisible to the compiler's wait counting
+  template <int SL, int X, int Y>
+  __device__ __forceinline__ void load(int tm0, int tn0, int pM, int pN, unsigned ldc, int wr, int wc, int g, int jr, int) {
+    const int nb = tn0 + Y * C::HN + wc * C::SN + CW * g;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = tm0 + X * C::HM + wr * C::SM + 16 * i + jr;
+      const unsigned ob = (m < pM && nb < pN) ? ((unsigned)m * ldc + (unsigned)nb) * 2u : OOB;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q[SL][i]) : "v"(ob), "s"(rsrc) : "memory");
+      if constexpr (CW == 12)
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:16" : "=v"(q2[SL][i]) : "v"(ob), "s"(rsrc) : "memory");
+    }
+  }
+  // counted wait that the uses of slot SL depend on (the registers pass through the statement)
+  template <int SL, int CNT>
+  __device__ __forceinline__ void wait() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (CW == 12)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q[SL][i]), "+v"(q2[SL][i]) : "n"(CNT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[SL][i]) : "n"(CNT) : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int SL>
+  __device__ __forceinline__ void add(int i, float* v) {
+    const i32x4_t a = q[SL][i];
+    v[0] += __uint_as_float((unsigned)a.x << 16); v[1] += __uint_as_float((unsigned)a.x & 0xffff0000u);
+    v[2] += __uint_as_float((unsigned)a.y << 16); v[3] += __uint_as_float((unsigned)a.y & 0xffff0000u);
+    v[4] += __uint_as_float((unsigned)a.z << 16); v[5] += __uint_as_float((unsigned)a.z & 0xffff0000u);
+    v[6] += __uint_as_float((unsigned)a.w << 16); v[7] += __uint_as_float((unsigned)a.w & 0xffff0000u);
+    if constexpr (CW == 12) {
+      const i32x2_t b = q2[SL][i];
+      v[8] += __uint_as_float((unsigned)b.x << 16); v[9] += __uint_as_float((unsigned)b.x & 0xffff0000u);
+      v[10] += __uint_as_float((unsigned)b.y << 16); v[11] += __uint_as_float((unsigned)b.y & 0xffff0000u);
+    }
+  }
+};
+
 // k-tile flavours
 constexpr int KT_PLAIN = 0;      // accumulate
 constexpr int KT_OPEN = 1;       // first k-tile of the workgroup's first tile: zero C operand
 constexpr int KT_FLUSH = 2;      // first k-tile of a later tile: zero C operand + flush of the previous tile, one quadrant per phase
 constexpr int KT_BIAS = 3;       // second k-tile of a tile: + the DMA piece that fetches the tile's bias into the wave's LDS slot
+constexpr int KT_SIDE = 4;       // last k-tile of a tile (E_RES): + the register loads of the tile's residual, quadrants 0 and 1
 
 template <class C, int EPI, class P>
 __device__ __forceinline__ void gemm8pp_body(const P& p) {
-  static_assert(EPI == 0 || EPI == E_GELU, "persistent kernel: bias / GELU epilogues");
+  static_assert(EPI == 0 || EPI == E_GELU || EPI == E_RES, "persistent kernel: bias / GELU / residual epilogues");
+  constexpr bool RES = (EPI & E_RES) != 0;
   constexpr int MT = C::MT, NT = C::NT, CW = 4 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -199,6 +273,9 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
   const char* bias_slot = smem + PCfg<C>::BIAS_OFF + wave * 1024;
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
   constexpr int NQ = MT * (CW == 12 ? 2 : 1) * ((EPI & E_GELU) ? 2 : 1);     // store instructions of one quadrant flush
+  constexpr int NL = RES ? MT * (CW == 12 ? 2 : 1) : 0;                      // load instructions of one quadrant's residual
+  Side<C, RES> side;
+  side.init(p.residual);
 
   auto stbf = [&](const auto& rs, unsigned off, const float (&src)[CW]) {
     i32x4_t q;
@@ -222,8 +299,8 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
   // quadrant (X, Y) of the tile at (pm0, pn0): NQ store instructions, no loads
   // (g_, jr_: the lane's column group / row -- parameters so that the trailing flush can derive them afresh instead of
   // keeping loop-invariant copies alive through the whole walk: the 256-column GELU variant sits at the 256-register limit)
-  auto flush = [&](auto xc, auto yc, int pm0, int pn0, int g_, int jr_) {
-    constexpr int X = decltype(xc)::value, Y = decltype(yc)::value;
+  auto flush = [&](auto xc, auto yc, int pm0, int pn0, int g_, int jr_, auto slotc) {
+    constexpr int X = decltype(xc)::value, Y = decltype(yc)::value, SL = decltype(slotc)::value;
     float bv[CW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -250,6 +327,7 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
           v[e + 1] = gg.y;
         }
       }
+      side.template add<SL>(i, v);       // E_RES: + residual, in float32: the sum is rounded once (as gemm8p_kernel does)
       stbf(rC, ob, v);
     }
   };
@@ -308,13 +386,18 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
   __builtin_amdgcn_s_barrier();
 
   // one k-tile = four phases (gemm8p_body's schedule); KIND adds the tile-boundary work to the load sections
-  auto ktile = [&](auto bufc, auto kindc, int pm0, int pn0, int n0) {
+  auto ktile = [&](auto bufc, auto kindc, int pm0, int pn0, int n0, int m0 = 0) {
     constexpr int BUFI = decltype(bufc)::value, KIND = decltype(kindc)::value;
     using BX = std::integral_constant<int, BUFI>;
     using BY = std::integral_constant<int, BUFI ^ 1>;
     using Z = std::integral_constant<int, (KIND == KT_OPEN || KIND == KT_FLUSH) ? 1 : 0>;
     const char* base = smem + BUFI * C::BUF;
     // phase 1
+    if constexpr (KIND == KT_SIDE) {                    // older than this k-tile's DMA pieces: its phase-4 wait retires them
+      side.template load<0, 0, 0>(m0, n0, pM, pN, ldc, wr, wc, g, jr, 0);
+      side.template load<1, 0, 1>(m0, n0, pM, pN, ldc, wr, wc, g, jr, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     readB(base + OB0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     readA(base + OA0);
@@ -324,8 +407,12 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT * 2) : "memory");
     if constexpr (KIND == KT_FLUSH) {
       __builtin_amdgcn_sched_barrier(0);
-      flush(I0{}, I0{}, pm0, pn0, g, jr);
+      flush(I0{}, I0{}, pm0, pn0, g, jr, I0{});
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (RES) {                              // quadrant (1, 1), flushed in phase 3, into the slot just consumed
+        side.template load<0, 1, 1>(pm0, pn0, pM, pN, ldc, wr, wc, g, jr, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     G8P_MFMA_PHASE(I0{}, I0{}, Z{}, fb0)
     // phase 2
@@ -334,8 +421,12 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
     stageB(I0{}, BX{});
     if constexpr (KIND == KT_FLUSH) {
       __builtin_amdgcn_sched_barrier(0);
-      flush(I0{}, I1{}, pm0, pn0, g, jr);
+      flush(I0{}, I1{}, pm0, pn0, g, jr, I1{});
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (RES) {                              // quadrant (1, 0), flushed in phase 4
+        side.template load<1, 1, 0>(pm0, pn0, pM, pN, ldc, wr, wc, g, jr, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     G8P_MFMA_PHASE(I0{}, I1{}, Z{}, fb1)
     // phase 3
@@ -344,13 +435,17 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
     stageA(I0{}, BX{});
     if constexpr (KIND == KT_FLUSH) {
       __builtin_amdgcn_sched_barrier(0);
-      flush(I1{}, I1{}, pm0, pn0, g, jr);
+      // younger than the request of quadrant (1, 1): phase 2's two DMA pieces, NQ stores and NL loads, this phase's two pieces
+      side.template wait<0, 4 + NQ + NL>();
+      flush(I1{}, I1{}, pm0, pn0, g, jr, I0{});
       __builtin_amdgcn_sched_barrier(0);
     }
     G8P_MFMA_PHASE(I1{}, I1{}, Z{}, fb1)
     // phase 4
     if constexpr (KIND == KT_FLUSH) {
-      flush(I1{}, I0{}, pm0, pn0, g, jr);
+      // younger than the request of quadrant (1, 0): phase 3's two DMA pieces and NQ stores
+      side.template wait<1, 2 + NQ>();
+      flush(I1{}, I0{}, pm0, pn0, g, jr, I1{});
       __builtin_amdgcn_sched_barrier(0);
     }
     stageB(I1{}, BX{});
@@ -360,12 +455,17 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 4 * NQ) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (KIND == KT_SIDE) {     // the same count again, with the residual registers passing through: defined from here on
+      side.template wait<0, 6>();
+      side.template wait<1, 6>();
+    }
     G8P_MFMA_PHASE(I1{}, I0{}, Z{}, fb0)
   };
   using KP = std::integral_constant<int, KT_PLAIN>;
   using KO = std::integral_constant<int, KT_OPEN>;
   using KF = std::integral_constant<int, KT_FLUSH>;
   using KB = std::integral_constant<int, KT_BIAS>;
+  using KS = std::integral_constant<int, KT_SIDE>;
 
   int pm0 = 0, pn0 = 0;
   bool first = true;
@@ -378,9 +478,18 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
     else
       ktile(I0{}, KF{}, pm0, pn0, n0);
     ktile(I1{}, KB{}, 0, 0, n0);
-    for (int kt = 2; kt < nkt; kt += 2) {
+    if constexpr (RES) {
+      for (int kt = 2; kt < nkt - 2; kt += 2) {
+        ktile(I0{}, KP{}, 0, 0, n0);
+        ktile(I1{}, KP{}, 0, 0, n0);
+      }
       ktile(I0{}, KP{}, 0, 0, n0);
-      ktile(I1{}, KP{}, 0, 0, n0);
+      ktile(I1{}, KS{}, 0, 0, n0, m0);      // the tile's last k-tile: + the residual of its quadrants 0 and 1
+    } else {
+      for (int kt = 2; kt < nkt; kt += 2) {
+        ktile(I0{}, KP{}, 0, 0, n0);
+        ktile(I1{}, KP{}, 0, 0, n0);
+      }
     }
     pm0 = m0;
     pn0 = n0;
@@ -394,10 +503,17 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
   int lane_f = lane;
   asm volatile("" : "+v"(lane_f));
   const int g_f = lane_f >> 4, jr_f = lane_f & 15;
-  flush(I0{}, I0{}, pm0, pn0, g_f, jr_f);
-  flush(I0{}, I1{}, pm0, pn0, g_f, jr_f);
-  flush(I1{}, I1{}, pm0, pn0, g_f, jr_f);
-  flush(I1{}, I0{}, pm0, pn0, g_f, jr_f);
+  flush(I0{}, I0{}, pm0, pn0, g_f, jr_f, I0{});
+  flush(I0{}, I1{}, pm0, pn0, g_f, jr_f, I1{});
+  if constexpr (RES) {
+    __builtin_amdgcn_sched_barrier(0);
+    side.template load<0, 1, 1>(pm0, pn0, pM, pN, ldc, wr, wc, g_f, jr_f, 0);
+    side.template load<1, 1, 0>(pm0, pn0, pM, pN, ldc, wr, wc, g_f, jr_f, 0);
+    side.template wait<0, 0>();
+    side.template wait<1, 0>();
+  }
+  flush(I1{}, I1{}, pm0, pn0, g_f, jr_f, I0{});
+  flush(I1{}, I0{}, pm0, pn0, g_f, jr_f, I1{});
 }
 
 template <class C, int EPI>

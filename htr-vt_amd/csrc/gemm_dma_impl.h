@@ -376,7 +376,18 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
       scalev[jp] = p.alpha * p.colscale[n < p.N ? n : 0];
     }
   }
-  if constexpr (MF == 16) {     // (no bias / colscale on this form: conv forward raw output and conv dgrad only)
+  if constexpr (MF == 16) {
+    // this lane's columns are 32 j + 16 b + (lane & 15): its own bias / scale values (the loads above were for column 32 j + cl)
+    float bias16[TNP][2], scale16[TNP][2];
+#pragma unroll
+    for (int jp = 0; jp < TNP; ++jp)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int n = n0 + (wn * TN + pass * TNP + jp) * 32 + 16 * b + (lane & 15);
+        const int nc = n < p.N ? n : 0;
+        bias16[jp][b] = (p.bias != nullptr && n < p.N) ? p.bias[nc] : 0.f;
+        scale16[jp][b] = (CSTATS && p.colscale != nullptr) ? p.alpha * p.colscale[nc] : p.alpha;
+      }
 #pragma unroll
     for (int jp = 0; jp < TNP; ++jp) {
       const int j = pass * TNP + jp;
@@ -396,7 +407,7 @@ __device__ __forceinline__ void epilogue_staged(f32x16_t (&acc)[2][TN], const P&
                 ds1[j][b] += x;
                 ds2[j][b] += x * x;
               }
-              v[r] = x * scalev[jp] + biasv[jp];
+              v[r] = x * scale16[jp][b] + bias16[jp][b];
             }
             uint2 o;
             o.x = pack_bf16x2(v[0], v[1]);

@@ -33,6 +33,54 @@ struct HaloGeo {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+
+// One k-tile (64 deep) of a wave's 64 x (32 TN) block from a halo A stage and a K-major B stage, on
+// v_mfma_f32_16x16x32_bf16: 4 x (2 TN) tiles of 16 x 16, two k-steps of 32.  Operand lane map: row l & 15, 16-byte k chunk
+// 4 s + (l >> 4).  Measured against the v_mfma_f32_32x32x16_bf16 form of the same loop (same bytes from LDS, same
+// cycles per FLOP): +2.4 ... +6 % on every stride-1 3x3 convolution of the stem, forward and dgrad
+// (profiles/r05_experiments.md) -- the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back,
+// item 7).  -DHTRVT_HALO_MFMA32 builds the former form (A/B runs).
+typedef float f32x4h_t __attribute__((ext_vector_type(4)));
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void halo_mma16(f32x4h_t (&a4)[2 * TM][2 * TN], const char* sa, const char* sb, int shift, int wm, int wn,
+                                           int lane) {
+  const int arow16 = wm * 64 + (lane & 15), ag = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8_t fa[2 * TM], fb[2 * TN];
+    const int chunk = 4 * s + ag;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) {
+      const int row = arow16 + i * 16 + shift;
+      fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa + row * 128 + ((chunk ^ Geo<256>::swz(row)) << 4)));
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+      const int row = wn * TN * 32 + j * 16 + (lane & 15);
+      fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + row * 128 + ((chunk ^ Geo<BN>::swz(row)) << 4)));
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j)
+        a4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], a4[i][j], 0, 0, 0);
+  }
+}
+// the four 16 x 16 tiles of 32 x 32 block (i, j) as registers 4 (2 a + b) + r of acc[i][j] (epilogue_staged<..., MF = 16>)
+template <int TM, int TN>
+__device__ __forceinline__ void halo_acc16_to_32(f32x16_t (&acc)[TM][TN], const f32x4h_t (&a4)[2 * TM][2 * TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][4 * (2 * a + b) + r] = a4[2 * i + a][2 * j + b][r];
+}
+
 // DGRAD = false: A rows = output pixels, source = x [B,H,W,Ci];  true: A rows = input pixels, source = dy [B,H,W,Co]
 template <int BN, bool DGRAD, class P>
 __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
@@ -114,39 +162,13 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
 
   // consumer fragment addressing: A row = wm*64 + i*32 + (lane & 31) + shift
   const int arow = wm * 64 + (lane & 31), ah = lane >> 5;
-#ifdef HTRVT_EXP_M16
-  // v_mfma_f32_16x16x32_bf16: the wave's 64 x (32 TN) block as 4 x (2 TN) tiles of 16 x 16, k-steps of 32.  Operand lane map:
-  // row l & 15, k chunk 4 s + (l >> 4); the four 16 x 16 tiles of 32 x 32 block (i, j) live in acc[i][j] as registers 4 (2 a + b) + r
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  f32x4_t a4[2 * TM][2 * TN];
+#ifndef HTRVT_HALO_MFMA32
+  f32x4h_t a4[2 * TM][2 * TN];
 #pragma unroll
   for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int arow16 = wm * 64 + (lane & 15), ag = lane >> 4;
-  auto compute = [&](const char* sa, const char* sb, int shift) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[2 * TM], fb[2 * TN];
-#pragma unroll
-      for (int i = 0; i < 2 * TM; ++i) {
-        const int row = arow16 + i * 16 + shift;
-        const int chunk = 4 * s + ag;
-        fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa + row * 128 + ((chunk ^ Geo<BM>::swz(row)) << 4)));
-      }
-#pragma unroll
-      for (int j = 0; j < 2 * TN; ++j) {
-        const int row = wn * TN * 32 + j * 16 + (lane & 15);
-        const int chunk = 4 * s + ag;
-        fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + row * 128 + ((chunk ^ Geo<BN>::swz(row)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < 2 * TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2 * TN; ++j)
-          a4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], a4[i][j], 0, 0, 0);
-    }
-  };
+    for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const char* sa, const char* sb, int shift) { halo_mma16<BN, TM, TN>(a4, sa, sb, shift, wm, wn, lane); };
 #else
   auto compute = [&](const char* sa, const char* sb, int shift) {
 #pragma unroll
@@ -211,17 +233,8 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
   if (!consumer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile
   __builtin_amdgcn_s_barrier();
 
-#ifdef HTRVT_EXP_M16
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][4 * (2 * a + b) + r] = a4[2 * i + a][2 * j + b][r];
+#ifndef HTRVT_HALO_MFMA32
+  halo_acc16_to_32<TM, TN>(acc, a4);
   epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
 #else
   epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer);
@@ -368,6 +381,14 @@ __device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x)
   }
   __builtin_amdgcn_s_barrier();
 
+#ifndef HTRVT_HALO_MFMA32
+  f32x4h_t a4[2 * TM][2 * TN];
+#pragma unroll
+  for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const char* sa, const char* sb, int shift) { halo_mma16<BN, TM, TN>(a4, sa, sb, shift, wm, wn, lane); };
+#else
   const int arow = wm * 64 + (lane & 31), ah = lane >> 5;
   auto compute = [&](const char* sa, const char* sb, int shift) {
 #pragma unroll
@@ -388,6 +409,8 @@ __device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
+
+#endif
 
   int bst = 0;                     // B stage of the k-tile being multiplied; the loaders fill (bst + 2) % 3
   int gs = 0, gc = 0;              // (slot, chunk) of group g
@@ -443,7 +466,12 @@ __device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x)
 
   // C rows: pixel (bimg, 2 hq + ca, sw (wq0 + r) + cb) of the NHWC gradient, r = 0 .. 255
   const int m0 = (bimg * p.Hi + 2 * hq + ca) * p.Wi + sw * wq0 + cb;
+#ifndef HTRVT_HALO_MFMA32
+  halo_acc16_to_32<TM, TN>(acc, a4);
+  epilogue_staged<TN, BN, BM, NW_TOTAL, true, false, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer, sw);
+#else
   epilogue_staged<TN, BN, BM, NW_TOTAL, true, false>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer, sw);
+#endif
 }
 
 template <int BN>

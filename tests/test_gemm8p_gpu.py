@@ -426,6 +426,38 @@ def test_persistent_gelu_epilogue(M, N, K, tiles):
     assert torch.equal(c2, outs[tiles[0]][0])
 
 
+@pytest.mark.parametrize("M,N,K", [(32768, 768, 768), (32768, 768, 3072), (16384, 768, 256), (16500, 780, 384)])
+def test_persistent_residual_epilogue(M, N, K):
+    """bias + residual (proj / fc2 forward) on the persistent kernel, the residual through inline-asm register loads
+    with counted waits (csrc/gemm8pp_impl.h, struct Side): exact on integer data (M / N tails, padded ldc), and -- the race
+    screen -- ten launches on random data bit-identical to the one-tile-per-workgroup kernel"""
+    ops = T._ops()
+    A, B = T._ints((M, K), lo=-2, hi=3, seed=31), T._ints((N, K), lo=-2, hi=3, seed=32)
+    bias = T._ints((N,), lo=-20, hi=21, seed=33)
+    res = T._ints((M, N + 8), lo=-30, hi=31, seed=34)
+    ref = (A @ B.t() + bias + res[:, :N]).to(BF).double()
+    a, b, r = A.to(BF).cuda(), B.to(BF).cuda(), res.to(BF).cuda()
+    c = torch.full((M, N + 8), 7.0, dtype=BF, device="cuda")
+    ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, bias=bias.float().cuda(), residual=r)
+    assert "gemm8pp_kernel<Cfg<192, 4, 2>, 1>" in _last_kernel(), _last_kernel()
+    got = c.double().cpu()
+    assert torch.equal(got[:, :N], ref), int((got[:, :N] != ref).sum())
+    assert (got[:, N:] == 7.0).all()
+    g = torch.Generator().manual_seed(35)
+    a = torch.randn(M, K, generator=g).to(BF).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.05).to(BF).cuda()
+    r = torch.randn(M, N, generator=g).to(BF).cuda()
+    biasf = torch.randn(N, generator=g).cuda()
+    want = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(a, b, want, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=biasf, residual=r, tile=11)
+    assert "gemm8p_kernel<" in _last_kernel()
+    for it in range(10):
+        c = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        ops.gemm(a, b, c, dtype=BF, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=biasf, residual=r)
+        assert "gemm8pp_kernel" in _last_kernel()
+        assert torch.equal(c, want), (it, int((c != want).sum()))
+
+
 def test_persistent_repeated_launches_are_bit_identical():
     """race screen: the folded flush reads accumulators the next phase overwrites and a bias slot the next tile's DMA
     refills; 20 launches of the model's qkv shape on random data must agree bit for bit with the first and with the

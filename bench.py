@@ -76,7 +76,7 @@ def parse():
                     "graph (Trainer.capture_step) inside the timed region instead of ~360 eager launches; on: captured on one "
                     "stream, multi: with the eager step's side streams (weight gradients, weight packs)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the strong-scaling sub-record (global batch "
-                    "128 split over the ranks, graph-replayed) that follows the timed weak-scaling steps")
+                    "128 split over the ranks; eager launches unless --graph on / multi) that follows the timed weak-scaling steps")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU iterations (about 10 s of host work in total)")
     return ap.parse_args()
@@ -118,7 +118,7 @@ def cpu_baseline(args, mask):
             O.loss_and_grads(sd, cfg, x, tg, tl, keep_mask=mask, train=True)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
-    out = {"value": round(args.cpu_batch / t, 3), "unit": "line-images/s", "cores": cores, "kind": "port",
+    out = {"value": round(args.cpu_batch / t, 3), "unit": "line-images/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
            "sample": f"{args.cpu_iters} timed iterations (1 warm-up) of batch {args.cpu_batch} 64x{args.width}, "
                      f"d{args.embed_dim}/{args.depth}L/{args.heads}h, "
                      f"{'eval forward + log_softmax' if args.forward_only else 'fwd+CTC+bwd (torch autograd over the oracle)'}"
@@ -203,8 +203,9 @@ def newest_traffic_json():
 
 
 def strong_leg(args, dev, world, rank, dtype, use_dist, steps=10, warmup=3):
-    """global batch `--batch` split evenly over the ranks, the step replayed as one HIP graph (eager if the capture is
-    refused), barrier + synchronize on both sides, max over ranks -- the same protocol as the main timed region"""
+    """global batch `--batch` split evenly over the ranks, eager launches unless --graph on / multi asks for the step replayed as
+    one HIP graph (and then eager again if the capture is refused), barrier + synchronize on both sides, max over ranks --
+    the same protocol as the main timed region"""
     from htrvt_amd.trainer import Trainer
     Bs = args.batch // world
     torch.manual_seed(123)
@@ -363,10 +364,21 @@ def main():
                 return l_
         elif args.graph != "off":
             tr.step(x, tg, tl, keep_mask=keep)          # lazily sized workspaces, one-time kernel attributes
-            gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True, single_stream=args.graph == "on")
+            gs = None
+            try:
+                gs = tr.capture_step(x, max_target_len=max(int(tl.max()), 1), masked=True, single_stream=args.graph == "on")
+            except Exception as e:      # noqa: BLE001 -- a refused capture (gloo, a collective that cannot be recorded): eager, and say so
+                print(f"bench.py: graph capture refused ({type(e).__name__}: {str(e)[:160]}); eager launches", file=sys.stderr)
+            if use_dist:                # every rank takes the same branch
+                flag = torch.tensor([1 if gs is not None else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    gs = None
+            if gs is None:
+                args.graph = "off"
 
             def one_step():
-                return gs.step(gs.img, tg, tl, keep_mask=keep)
+                return gs.step(gs.img, tg, tl, keep_mask=keep) if gs is not None else tr.step(x, tg, tl, keep_mask=keep)
         else:
             def one_step():
                 return tr.step(x, tg, tl, keep_mask=keep)
@@ -488,10 +500,8 @@ def main():
         if (not args.no_parity_path and world == 1 and args.dtype == "bf16" and not args.forward_only and not args.sam
                 and args.scaling == "weak"):
             out["parity_path"] = parity_path(args, dev, x, tg, tl, keep)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:     # rank 0, after the timed region (N > 1: the other ranks wait at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(args, keep)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

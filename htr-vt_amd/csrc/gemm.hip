@@ -417,6 +417,20 @@ extern "C" int htrvt_gemm_dgrad_merged_tiles(const HtrvtGemmDesc* d) {
 
 static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int zdim, hipStream_t st);
 
+// every operand of the launch (A / the gathered tensor, B, C and its same-shaped side inputs) inside one 2 GiB buffer descriptor
+static bool operands_below_2gib(const HtrvtGemmDesc* d) {
+  const long long lim = (1ll << 31) - 64, es = d->dtype == HTRVT_BF16 ? 2 : 4;
+  long long a, b, c;
+  if (d->gather == HTRVT_GATHER_CONV_FWD || d->gather == HTRVT_GATHER_CONV_WGRAD) a = (long long)d->nB * d->Hi * d->Wi * d->Ci * es;
+  else if (d->gather == HTRVT_GATHER_CONV_DGRAD) a = (long long)d->nB * d->Ho * d->Wo * d->Co * es;
+  else a = (d->a_layout == HTRVT_KMAJOR ? (long long)d->M : (long long)d->K) * d->lda * es;
+  if (d->gather == HTRVT_GATHER_CONV_WGRAD) b = (long long)d->K * d->ldb * es;
+  else b = (d->b_layout == HTRVT_KMAJOR ? (long long)d->N : (long long)d->K) * d->ldb * es;
+  const long long crows = (d->gather == HTRVT_GATHER_CONV_DGRAD && d->cls_h >= 0) ? (long long)d->nB * d->Hi * d->Wi : d->M;
+  c = crows * d->ldc * (d->c_f32 ? 4 : es);
+  return a < lim && b < lim && c < lim;
+}
+
 extern "C" int htrvt_gemm(const HtrvtGemmDesc* d, void* stream) {
   HTRVT_REQUIRE(d != nullptr, "htrvt_gemm: null descriptor");
   HTRVT_REQUIRE(d->dtype == HTRVT_F32 || d->dtype == HTRVT_BF16, "htrvt_gemm: bad dtype %d", d->dtype);
@@ -574,6 +588,14 @@ static int launch_main(const HtrvtGemmDesc* d, KParams& p, int bm, int bn, int z
     r = gemm_dma_try_launch(d, q, zdim, st);     // one barrier per k-tile, LDS-staged epilogue (gemm_dma.hip)
     if (r != 0) return r < 0 ? r : 0;
   }
+  // Past this point the register-staged kernel (64-bit addressing, 128-row tiles) takes the launch.  Forms that exist in
+  // the LDS-DMA families only -- whose operands go through 2 GiB buffer descriptors -- are REFUSED here, never rerouted:
+  // a parity class / merged strided dgrad, fused backward epilogues, per-tile column sums sized for 256-row tiles, and any
+  // explicit family selector (tile 2 .. 17) the caller asked for.  (Round 4's memory fault was such a reroute: the tripled
+  // layer-1 operand of the split-bf16 path passed 2 GiB at 128 images, the LDS-DMA family declined, and the 128-row
+  // fallback wrote 8 192 rows of column sums into a buffer htrvt_gemm_num_mtiles had sized for 4 096 -- 6 MB past its end.)
+  HTRVT_REQUIRE(!(d->dtype == HTRVT_BF16 && d->tile >= 2 && d->tile <= 17 && !operands_below_2gib(d)),
+                "htrvt_gemm: tile selector %d names an LDS-DMA kernel family; its operands must stay below 2 GiB: split the launch", d->tile);
   HTRVT_REQUIRE(!cls, "htrvt_gemm: parity-class dgrad is served by the LDS-DMA kernel only (M > 128, operands < 2 GiB)");
   HTRVT_REQUIRE(d->cls_h != -2, "htrvt_gemm: the merged strided dgrad (cls_h = -2) is served by the halo kernels only; ask htrvt_gemm_dgrad_merged_tiles first");
   // per-tile column sums: the caller sized `colstats` with htrvt_gemm_num_mtiles, i.e. for the 256-row tiles of the LDS-DMA

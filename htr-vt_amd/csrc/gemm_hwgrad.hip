@@ -51,7 +51,14 @@ int gemm_hwgrad_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStre
 // host query for the split-K heuristic of the caller: workgroups per K range, tile rows, tile columns of the launch the
 // halo-staged weight-gradient kernel would make for this descriptor; 0 when the generic kernels serve it
 extern "C" int htrvt_gemm_wgrad_tiling(const HtrvtGemmDesc* d, int* tile_rows, int* tile_cols) {
-  if (d == nullptr || !htrvt::gemm_hwgrad_serves(d)) return 0;
+  if (d == nullptr) return 0;
+  if (d->gather == HTRVT_GATHER_NONE) {      // a Linear weight gradient dW = dy^T x: the MN-major 8-phase kernel's 256 x 256 tiles (gemm8p.hip)
+    if (!htrvt::gemm8pt_serves(d) || !(d->split_k > 1 ? d->accumulate != 0 : d->accumulate == 0)) return 0;
+    if (tile_rows) *tile_rows = 256;
+    if (tile_cols) *tile_cols = 256;
+    return ((d->M + 255) / 256) * ((d->N + 255) / 256);
+  }
+  if (!htrvt::gemm_hwgrad_serves(d)) return 0;
   if (tile_rows) *tile_rows = 3 * htrvt::gemm_hwgrad_cc(d);
   if (tile_cols) *tile_cols = htrvt::gemm_hwgrad_bn(d);
   return htrvt::gemm_hwgrad_tiles(d);

@@ -19,7 +19,9 @@ constexpr int NT_ = 256;
 __device__ __forceinline__ void split1(float x, float& hi, float& lo) {
   const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)x);      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
   hi = __uint_as_float((unsigned)h << 16);
-  const float d = x - hi;                                                       // exact in float32 (|x - hi| <= half an ulp of hi)
+  // x - hi is exact in float32 (|x - hi| <= half an ulp of hi); hi = +-Inf (x infinite, or finite but beyond bf16's range):
+  // lo = 0, so that hi + lo stays Inf as on the float32 path instead of Inf - Inf = NaN
+  const float d = (h & 0x7fffu) == 0x7f80u ? 0.f : x - hi;
   const unsigned short l = __builtin_bit_cast(unsigned short, (__bf16)d);
   lo = __uint_as_float((unsigned)l << 16);                                      // the bf16 value itself, also in the float32 copies
 }

@@ -194,9 +194,14 @@ class Engine:
     def _batch_slices(B, nbytes, rows_per_image):
         """smallest number of equal batch slices that keeps an operand of `nbytes` below 2 GiB per launch (M tiles of 256
         rows must not straddle slices: the per-tile column sums are concatenated)"""
+        def fits(n):
+            return B % n == 0 and nbytes // n < 2 ** 31 - 4096 and (n == 1 or (B // n * rows_per_image) % 256 == 0)
         n = 1
-        while n < B and (B % n or nbytes // n >= 2 ** 31 - 4096 or (n > 1 and (B // n * rows_per_image) % 256)):
+        while n < B and not fits(n):
             n += 1
+        if not fits(n):
+            raise ValueError(f"no batch slicing of {B} images keeps a {nbytes}-byte operand below 2 GiB per launch with whole 256-row tiles "
+                             f"({rows_per_image} rows per image)")
         return n
 
     def _split_act(self, t, cols, cat=True, planes=False):
@@ -464,10 +469,20 @@ class Engine:
         M, N = dy.shape
         K = x.shape[1]
         tiling = None
-        t256 = ((N + 255) // 256) * ((K + 255) // 256)
-        if (self.gdt == torch.bfloat16 and self.deterministic and not plain and min(N, K, M) >= 256 and N % 8 == 0 and K % 8 == 0 and t256 >= 16
-                and os.environ.get("HTRVT_NO_MNMAJOR_8PHASE") != "1"):
-            tiling = (t256, 256, 256)     # the 8-phase MN-major kernel's tiles (csrc/gemm8pt_impl.h; gemm8pt_serves' conditions)
+        if self.gdt == torch.bfloat16 and self.deterministic and not plain:
+            # the MN-major 8-phase kernel's 256 x 256 tiles where the LIBRARY says it serves the launch (htrvt_gemm_wgrad_tiling:
+            # gemm8pt_serves -- alignment, 2 GiB, the HTRVT_NO_MNMAJOR_8PHASE switch; no copy of that test here)
+            import ctypes
+            from ._lib import GemmDesc
+            d = GemmDesc()
+            d.dtype, d.a_layout, d.b_layout, d.gather = dt(self.gdt), MNMAJOR, MNMAJOR, 0
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = N, K, M, (3 * N if self.split else N), K, K
+            d.batch, d.split_k, d.c_f32, d.accumulate = 1, 2, 1, 1
+            d.A, d.B, d.C = ptr(dy), ptr(x), ptr(dw)
+            tr_, tc_ = ctypes.c_int32(0), ctypes.c_int32(0)
+            nt = lib.htrvt_gemm_wgrad_tiling(ctypes.byref(d), ctypes.byref(tr_), ctypes.byref(tc_))
+            if nt > 0:
+                tiling = (nt, tr_.value, tc_.value)
         sk = self._split_k(N, K, M, tiling=tiling)
         if self.split and not plain:      # the contraction runs over the rows: hi / lo planes, three accumulating launches
             # MN-major plain operands carry their own leading dimension: the hi / lo planes of the gradient are column blocks

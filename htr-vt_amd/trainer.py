@@ -247,6 +247,9 @@ class GraphedStep:
         self._h_keep = torch.ones(N, dtype=torch.float32).pin_memory()
         self._h_hyper = torch.zeros(HTRVT_ADAMW_SCALARS, dtype=torch.float32).pin_memory()
         self._staged = None
+        # the recorded launches bake the engine's execution plan: its boolean switches (and the override environment that
+        # sets them) must be the same at every replay
+        self._plan = self._engine_plan(eng)
         fl.check_views()
         mark_weights_dirty(tr.model)       # the recorded forward must contain the weight re-layout launch
         self.graph = torch.cuda.CUDAGraph()
@@ -270,17 +273,28 @@ class GraphedStep:
             eng.single_stream = saved_single
         mark_weights_dirty(tr.model)
 
+    @staticmethod
+    def _engine_plan(eng):
+        import os
+        return (tuple(sorted((k, v) for k, v in vars(eng).items() if isinstance(v, bool) and k not in ("capturing", "single_stream", "_side_active", "_bn_train", "_saving"))),
+                os.environ.get("HTRVT_ENGINE_OVERRIDE", ""))
+
     def step(self, img, targets, lengths, keep_mask=None, lr=None):
         """one replay; returns the (device, reused) mean-loss tensor of this step"""
         from ._lib import lib
         np, tr = self.np, self.tr
         tr.flat.check_views()
+        if self._engine_plan(tr.engine) != self._plan:
+            raise RuntimeError("GraphedStep: the engine's switches changed since the capture (the graph holds the launches of the "
+                               "plan it was recorded with): capture the step again")
         if self._staged is not None:
             self._staged.synchronize()      # previous step's host->device copies have run: the pinned buffers are free
         tl = np.asarray(lengths, dtype=np.int32).reshape(-1)
         tg = np.asarray(targets, dtype=np.int32).reshape(-1)
         if tl.shape[0] != self.B or (tl.size and int(tl.max()) > self.maxlen) or tg.shape[0] > self._h_tg.numel():
             raise ValueError(f"GraphedStep was captured for {self.B} lines of <= {self.maxlen} labels")
+        if tg.shape[0] != int(tl.sum()):     # the offsets below index the label buffer: a short `targets` would leave an earlier step's labels in reach
+            raise ValueError(f"GraphedStep: {tg.shape[0]} labels for lengths that sum to {int(tl.sum())}")
         off = np.zeros_like(tl)
         if tl.size > 1:
             off[1:] = np.cumsum(tl[:-1])

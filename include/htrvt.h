@@ -121,7 +121,8 @@ typedef struct HtrvtGemmDesc {
 int htrvt_gemm(const HtrvtGemmDesc* d, void* stream);
 /* rows of colstats (= number of M tiles) the call above will write for this desc */
 int htrvt_gemm_num_mtiles(const HtrvtGemmDesc* d);
-/* Weight-gradient launches (gather = HTRVT_GATHER_CONV_WGRAD): which tiling htrvt_gemm would use.  Returns the number of
+/* Weight-gradient launches (gather = HTRVT_GATHER_CONV_WGRAD; or gather = 0 with both operands MN-major and float32 output: a
+ * Linear weight gradient, 256 x 256 tiles when the MN-major 8-phase kernel serves it): which tiling htrvt_gemm would use.  Returns the number of
  * workgroups per K range and the tile extents when the halo-staged kernel (3x3, W stride 1, row length a multiple of 64,
  * Cpad a multiple of 64, float32 output, operands inside 2 GiB) serves the descriptor, 0 when the generic kernels do: the
  * caller's split-K choice must count the workgroups of the kernel that actually runs. */

@@ -140,7 +140,7 @@ struct PLoadB {
 
 // The residual of two quadrants in flight / in use (E_RES): q[slot][i] = columns 0-7, q2[slot][i] = columns 8-11 (CW = 12) of row
 // tile i.  ON = false: no state, no code (the other epilogues compile exactly as before).
-template <class C, bool ON>
+template <class C, int MODE>       // MODE 0: no side input; 1: + residual; 2: * GELU'(saved pre-activation)
 struct Side {
   __device__ __forceinline__ void init(const void*) {}
   template <int SL, int X, int Y>
@@ -150,8 +150,8 @@ struct Side {
   template <int SL>
   __device__ __forceinline__ void add(int, float*) {}
 };
-template <class C>
-struct Side<C, true> {
+template <class C, int MODE>
+struct SideOn {
   static constexpr int MT = C::MT, CW = 4 * C::NT;
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
   i32x4_t q[2][MT];
@@ -189,17 +189,33 @@ struct Side<C, true> {
   template <int SL>
   __device__ __forceinline__ void add(int i, float* v) {
     const i32x4_t a = q[SL][i];
-    v[0] += __uint_as_float((unsigned)a.x << 16); v[1] += __uint_as_float((unsigned)a.x & 0xffff0000u);
-    v[2] += __uint_as_float((unsigned)a.y << 16); v[3] += __uint_as_float((unsigned)a.y & 0xffff0000u);
-    v[4] += __uint_as_float((unsigned)a.z << 16); v[5] += __uint_as_float((unsigned)a.z & 0xffff0000u);
-    v[6] += __uint_as_float((unsigned)a.w << 16); v[7] += __uint_as_float((unsigned)a.w & 0xffff0000u);
+    float x[CW];
+    x[0] = __uint_as_float((unsigned)a.x << 16); x[1] = __uint_as_float((unsigned)a.x & 0xffff0000u);
+    x[2] = __uint_as_float((unsigned)a.y << 16); x[3] = __uint_as_float((unsigned)a.y & 0xffff0000u);
+    x[4] = __uint_as_float((unsigned)a.z << 16); x[5] = __uint_as_float((unsigned)a.z & 0xffff0000u);
+    x[6] = __uint_as_float((unsigned)a.w << 16); x[7] = __uint_as_float((unsigned)a.w & 0xffff0000u);
     if constexpr (CW == 12) {
       const i32x2_t b = q2[SL][i];
-      v[8] += __uint_as_float((unsigned)b.x << 16); v[9] += __uint_as_float((unsigned)b.x & 0xffff0000u);
-      v[10] += __uint_as_float((unsigned)b.y << 16); v[11] += __uint_as_float((unsigned)b.y & 0xffff0000u);
+      x[8] = __uint_as_float((unsigned)b.x << 16); x[9] = __uint_as_float((unsigned)b.x & 0xffff0000u);
+      x[10] = __uint_as_float((unsigned)b.y << 16); x[11] = __uint_as_float((unsigned)b.y & 0xffff0000u);
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) v[e] += x[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < CW; e += 2) {
+        const f32x2_t gg = gelu_erf_grad_fast2(f32x2_t{x[e], x[e + 1]});
+        v[e] *= gg.x;
+        v[e + 1] *= gg.y;
+      }
     }
   }
 };
+template <class C>
+struct Side<C, 1> : SideOn<C, 1> {};
+template <class C>
+struct Side<C, 2> : SideOn<C, 2> {};
 
 // k-tile flavours
 constexpr int KT_PLAIN = 0;      // accumulate
@@ -210,8 +226,8 @@ constexpr int KT_SIDE = 4;       // last k-tile of a tile (E_RES): + the registe
 
 template <class C, int EPI, class P>
 __device__ __forceinline__ void gemm8pp_body(const P& p) {
-  static_assert(EPI == 0 || EPI == E_GELU || EPI == E_RES, "persistent kernel: bias / GELU / residual epilogues");
-  constexpr bool RES = (EPI & E_RES) != 0;
+  static_assert(EPI == 0 || EPI == E_GELU || EPI == E_RES || EPI == E_GELUGRAD, "persistent kernel: bias / GELU / residual / GELU' epilogues");
+  constexpr bool RES = (EPI & (E_RES | E_GELUGRAD)) != 0;          // a side input per element (struct Side)
   constexpr int MT = C::MT, NT = C::NT, CW = 4 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -274,8 +290,8 @@ __device__ __forceinline__ void gemm8pp_body(const P& p) {
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
   constexpr int NQ = MT * (CW == 12 ? 2 : 1) * ((EPI & E_GELU) ? 2 : 1);     // store instructions of one quadrant flush
   constexpr int NL = RES ? MT * (CW == 12 ? 2 : 1) : 0;                      // load instructions of one quadrant's residual
-  Side<C, RES> side;
-  side.init(p.residual);
+  Side<C, (EPI & E_RES) ? 1 : ((EPI & E_GELUGRAD) ? 2 : 0)> side;
+  side.init((EPI & E_GELUGRAD) ? (const void*)p.preact : (const void*)p.residual);
 
   auto stbf = [&](const auto& rs, unsigned off, const float (&src)[CW]) {
     i32x4_t q;

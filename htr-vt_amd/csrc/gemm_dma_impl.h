@@ -962,6 +962,28 @@ __device__ __forceinline__ void gemm_dma_body(const P& p, const int block_x) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha1[i], hb1[j], acc[i][j], 0, 0, 0);
     }
 #endif
+  } else if (SPEC && consumer) {
+    // loader-wave kernels (round 5): the MFMA waves run their OWN copy of the loop -- fragment reads and MFMAs between barriers,
+    // nothing else -- instead of walking the loaders' branches (gemm_halo_impl.h: -5 ... -9 % per launch on the halo kernels)
+    for (int kt = 0; kt < nkt; ++kt) {
+      const char* sa = smem + a_cur * A_BYTES;
+      const char* sb = smem + B_BASE + b_cur * B_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, AL>(sa, wm * TM + i, s, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BL>(sb, wn * TN + j, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_barrier();
+      advance();
+    }
   } else {
   for (int kt = 0; kt < nkt; ++kt) {
     const char* sa = smem + a_cur * A_BYTES;

@@ -1,5 +1,7 @@
 // gemm_halo.hip -- instantiations + host-side eligibility of the halo-staged 3x3 stride-1 convolution kernels
 // (gemm_halo_impl.h); called from gemm_dma_try_launch before the generic gather kernels.
+#include <stdlib.h>
+
 #include "gemm_halo_impl.h"
 
 namespace htrvt {

@@ -83,7 +83,7 @@ __device__ __forceinline__ void halo_acc16_to_32(f32x16_t (&acc)[TM][TN], const 
 
 // DGRAD = false: A rows = output pixels, source = x [B,H,W,Ci];  true: A rows = input pixels, source = dy [B,H,W,Co]
 template <int BN, bool DGRAD, class P>
-__device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
+__device__ __forceinline__ void gemm_halo_body_oneloop(const P& p, const int block_x) {
   using H = HaloGeo<BN>;
   constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -362,72 +362,57 @@ __device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x)
     lb.template issue<true>(p, lds0 + H::B_BASE + bst * H::B_STAGE, k0, kend, lw);
   };
 
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // C rows: pixel (bimg, 2 hq + ca, sw (wq0 + r) + cb) of the NHWC gradient, r = 0 .. 255
+  const int m0 = (bimg * p.Hi + 2 * hq + ca) * p.Wi + sw * wq0 + cb;
 
-  // ---- prologue: halo tile of group 0, B of k-tiles 0 and 1 ----
-  if (!consumer) {
+  // Consumer and loader waves run SEPARATE copies of the loop (same barriers): straight-line fragment reads + MFMAs between
+  // barriers on one side, nothing but address arithmetic and DMA issue on the other (gemm_halo_body: -4 ... -8 % per launch
+  // against the one-loop form in which every wave walked both sides' branches).
+  if (consumer) {
+    f32x4h_t a4[2 * TM][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();
+    int bst = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      const int n = g < nmain ? ncol : 1;
+      const char* sa = smem + (g & 1) * H::A_STAGE;
+      for (int j = 0; j < n; ++j) {
+        const int shift = g < nmain ? (shp >> (2 * j)) & 3 : 1;
+        halo_mma16<BN, TM, TN>(a4, sa, smem + H::B_BASE + bst * H::B_STAGE, shift, wm, wn, lane);
+        __builtin_amdgcn_s_barrier();
+        bst = bst == 2 ? 0 : bst + 1;
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+    halo_acc16_to_32<TM, TN>(acc, a4);
+    epilogue_staged<TN, BN, BM, NW_TOTAL, true, false, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true, sw);
+  } else {
+    // ---- prologue: halo tile of group 0, B of k-tiles 0 and 1 ----
     const unsigned gb0 = group_base(0, 0, nslot, nrow, abase0, abase1, abasex);
     issueA(0, 0, gb0, 0);
     issueA(1, 0, gb0, 0);
     issueB(0);
     issueB(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-#ifndef HTRVT_HALO_MFMA32
-  f32x4h_t a4[2 * TM][2 * TN];
-#pragma unroll
-  for (int i = 0; i < 2 * TM; ++i)
-#pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](const char* sa, const char* sb, int shift) { halo_mma16<BN, TM, TN>(a4, sa, sb, shift, wm, wn, lane); };
-#else
-  const int arow = wm * 64 + (lane & 31), ah = lane >> 5;
-  auto compute = [&](const char* sa, const char* sb, int shift) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = arow + i * 32 + shift;
-        const int chunk = 2 * s + ah;
-        fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa + row * 128 + ((chunk ^ Geo<BM>::swz(row)) << 4)));
+    __builtin_amdgcn_s_barrier();
+    int bst = 0;                     // B stage of the k-tile being multiplied; the loaders fill (bst + 2) % 3
+    int gs = 0, gc = 0;              // (slot, chunk) of group g
+    for (int g = 0; g < ngroups; ++g) {
+      const int n = g < nmain ? ncol : 1;
+      int ns = gs, nc = gc + 1;      // group g + 1
+      if (nc == NC) {
+        nc = 0;
+        ++ns;
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, HTRVT_KMAJOR>(sb, wn * TN + j, s, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-#endif
-
-  int bst = 0;                     // B stage of the k-tile being multiplied; the loaders fill (bst + 2) % 3
-  int gs = 0, gc = 0;              // (slot, chunk) of group g
-  for (int g = 0; g < ngroups; ++g) {
-    const int n = g < nmain ? ncol : 1;
-    int ns = gs, nc = gc + 1;      // group g + 1
-    if (nc == NC) {
-      nc = 0;
-      ++ns;
-    }
-    const unsigned ngb = group_base(ns, nc, nslot, nrow, abase0, abase1, abasex);
-    const char* sa = smem + (g & 1) * H::A_STAGE;
-    const int nast = (g + 1) & 1;
-    for (int j = 0; j < n; ++j) {
-      const bool last = j == n - 1;
-      const int fill = bst >= 1 ? bst - 1 : 2;          // (bst + 2) % 3
-      if (!consumer) {
+      const unsigned ngb = group_base(ns, nc, nslot, nrow, abase0, abase1, abasex);
+      const int nast = (g + 1) & 1;
+      for (int j = 0; j < n; ++j) {
+        const bool last = j == n - 1;
+        const int fill = bst >= 1 ? bst - 1 : 2;          // (bst + 2) % 3
         if (n == 1) {             // both halves of the next halo tile, then B: the wait below covers the halo tile
           issueA(0, nast, ngb, nc);
           issueA(1, nast, ngb, nc);
@@ -451,27 +436,23 @@ __device__ __forceinline__ void gemm_halo_s2_body(const P& p, const int block_x)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
           }
         }
-      } else {
-        const int shift = g < nmain ? (shp >> (2 * j)) & 3 : 1;
-        compute(sa, smem + H::B_BASE + bst * H::B_STAGE, shift);
+        __builtin_amdgcn_s_barrier();
+        bst = bst == 2 ? 0 : bst + 1;
       }
-      __builtin_amdgcn_s_barrier();
-      bst = bst == 2 ? 0 : bst + 1;
+      gs = ns;
+      gc = nc;
     }
-    gs = ns;
-    gc = nc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    epilogue_staged<TN, BN, BM, NW_TOTAL, true, false, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, false, sw);
   }
-  if (!consumer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces issued past the last k-tile
-  __builtin_amdgcn_s_barrier();
-
-  // C rows: pixel (bimg, 2 hq + ca, sw (wq0 + r) + cb) of the NHWC gradient, r = 0 .. 255
-  const int m0 = (bimg * p.Hi + 2 * hq + ca) * p.Wi + sw * wq0 + cb;
-#ifndef HTRVT_HALO_MFMA32
-  halo_acc16_to_32<TM, TN>(acc, a4);
-  epilogue_staged<TN, BN, BM, NW_TOTAL, true, false, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer, sw);
-#else
-  epilogue_staged<TN, BN, BM, NW_TOTAL, true, false>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, consumer, sw);
-#endif
 }
 
 template <int BN>
@@ -484,21 +465,150 @@ __global__ __launch_bounds__(768) void gemm_halo_s2_kernel(const KParams p) {
 
 template <int BN>
 int launch_halo_s2(const KParams& p, hipStream_t st) {
-  using H = HaloGeo<BN>;
+  constexpr int LDS = HaloGeo<BN>::LDS_BYTES;
   static bool attr_done = false;
   auto kern = gemm_halo_s2_kernel<BN>;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(%d B LDS): %s", H::LDS_BYTES, hipGetErrorString(e));
+      set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
       return -2;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), H::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), LDS, st, p);
   set_last_kernel("gemm_halo_s2_kernel<%d>", BN);
   const int rc = check_launch("gemm_halo_s2_kernel");
   return rc ? rc : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_halo_body, round 5: consumer and loader waves run SEPARATE copies of the loop (same barriers) -- straight-line fragment
+// reads + MFMAs between barriers on one side, nothing but address arithmetic and DMA issue on the other.  In the one-loop form
+// above every wave walked both sides' branches and the register allocation, the scalar state and the instruction stream of
+// either role carried the other's: same-box A/B -5 ... -9 % per launch on every stride-1 3x3 convolution of the stem
+// (profiles/r05_experiments.md).  The epilogue is inlined once per role (the loader copy with a dead accumulator set).
+// ---------------------------------------------------------------------------------------------
+// (DGRAD / forward and the row stride as in gemm_halo_body_oneloop above)
+template <int BN, bool DGRAD, class P>
+__device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
+  using H = HaloGeo<BN>;
+  constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = block_x;
+  if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Hh = DGRAD ? p.Ho : p.Hi, Ww = DGRAD ? p.Wo : p.Wi, Cs = DGRAD ? p.Co : p.Ci;   // gathered tensor [B,Hh,Ww,Cs]
+  const int rowi = m0 / Ww, w0 = m0 - rowi * Ww;
+  const int Hm = DGRAD ? Hh : p.Ho;                     // forward with a row stride: M rows are OUTPUT rows
+  const int bimg = rowi / Hm, hrow = rowi - bimg * Hm;
+  const int NC = p.Cpad / BK;
+  const int NG = 3 * NC;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (wave >> 1) & 3, wn = wave & 1;
+
+  if (wave < NWC) {
+    // ================================ consumer waves: fragments + MFMA, nothing else ================================
+    f32x4h_t a4[2 * TM][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();
+    for (int g = 0; g < NG; ++g) {
+      const char* sa = smem + (g & 1) * H::A_STAGE;
+      halo_mma16<BN, TM, TN>(a4, sa, smem + H::B_BASE + 0 * H::B_STAGE, DGRAD ? 2 : 0, wm, wn, lane);
+      __builtin_amdgcn_s_barrier();
+      halo_mma16<BN, TM, TN>(a4, sa, smem + H::B_BASE + 1 * H::B_STAGE, 1, wm, wn, lane);
+      __builtin_amdgcn_s_barrier();
+      halo_mma16<BN, TM, TN>(a4, sa, smem + H::B_BASE + 2 * H::B_STAGE, DGRAD ? 0 : 2, wm, wn, lane);
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+    halo_acc16_to_32<TM, TN>(acc, a4);
+    epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+  } else {
+    // ================================ loader waves: LDS-DMA of the operands, then the side tile ================================
+    const int lw = (wave - NWC) & 3;
+    __builtin_amdgcn_s_setprio(3);
+    DmaLoader<BN, HTRVT_KMAJOR, 0, 4> lb;
+    lb.init(p, p.B, p.ldb, n0, p.N, lw, lane);
+    const unsigned long long ba = (unsigned long long)p.A;
+    const i32x4_t rsrcA = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
+    const int rho0 = lw * 8 + (lane >> 3);
+    const int cgA = (lane & 7) ^ Geo<BM>::swz(rho0);
+    const unsigned lane_off = (unsigned)((w0 - 1 + rho0) * Cs + cgA * 8) * 2u;
+    const unsigned lds0 = lds_addr_of(smem);
+    auto issueA = [&](int half, int ast, int gdy, int gcc) {
+      const int hh = DGRAD ? hrow + 1 - gdy : hrow * p.sh + gdy - 1;
+      const bool rowok = (unsigned)hh < (unsigned)Hh;
+      const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww) * Cs + gcc * BK) * 2u;
+      const bool chok = gcc * BK + cgA * 8 < Cs;
+#pragma unroll
+      for (int i = 0; i < H::NP_AH; ++i) {
+        const int ii = half * H::NP_AH + i;
+        const int rho = rho0 + 32 * ii;
+        const int w = w0 - 1 + rho;
+        const bool v = rowok && chok && rho < 258 && (unsigned)w < (unsigned)Ww;
+        const unsigned voff = v ? gbase + lane_off + (unsigned)(32 * ii * Cs) * 2u : OOB;
+        dma16(rsrcA, __builtin_amdgcn_readfirstlane(lds0 + ast * H::A_STAGE + (lw + 4 * ii) * 1024), voff);
+      }
+    };
+    auto issueB = [&](int bst, int gdy, int gcc, int dx) {
+      lb.template issue<true>(p, lds0 + H::B_BASE + bst * H::B_STAGE, (gdy * 3 + dx) * p.Cpad + gcc * BK, p.K, lw);
+    };
+    // ---- prologue: halo tile of group 0, B of k-tiles 0 and 1 ----
+    issueA(0, 0, 0, 0);
+    issueA(1, 0, 0, 0);
+    issueB(0, 0, 0, 0);
+    issueB(1, 0, 0, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int gdy = 0, gcc = 0;
+    for (int g = 0; g < NG - 1; ++g) {       // every group but the last: the schedule of gemm_halo_body
+      int ndy = gdy, ncc = gcc + 1;
+      if (ncc == NC) {
+        ncc = 0;
+        ++ndy;
+      }
+      const int nast = (g + 1) & 1;
+      issueB(2, gdy, gcc, 2);
+      issueA(0, nast, ndy, ncc);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B + H::NP_AH) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issueB(0, ndy, ncc, 0);
+      issueA(1, nast, ndy, ncc);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B + H::NP_AH) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issueB(1, ndy, ncc, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+      __builtin_amdgcn_s_barrier();
+      gdy = ndy;
+      gcc = ncc;
+    }
+    // ---- last group: its third B tile, nothing left to stage for a next group ----
+    issueB(2, gdy, gcc, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, false);
+  }
 }
 
 template <int BN, bool DGRAD>
@@ -506,7 +616,11 @@ __global__ __launch_bounds__(768) void gemm_halo_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;
   (void)p;
   KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef HTRVT_HALO_ONELOOP      // A/B builds: consumer and loader waves in ONE copy of the loop (rounds 3-4)
+  gemm_halo_body_oneloop<BN, DGRAD>(*kp, (int)blockIdx.x);
+#else
   gemm_halo_body<BN, DGRAD>(*kp, (int)blockIdx.x);
+#endif
 }
 
 template <int BN, bool DGRAD>

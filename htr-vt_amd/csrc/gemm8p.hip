@@ -122,7 +122,7 @@ int gemm8pt_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t
 // returns 1 if it launched, 0 if this family has no kernel for the call, < 0 on error
 int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t st) {
   if (!gemm8p_serves(d)) return 0;
-  int bn = gemm8p_pick_bn(d);
+  const int bn = gemm8p_pick_bn(d);
   int epi = 0;
   if (d->residual != nullptr) epi |= E_RES;
   if (d->act == 1) epi |= E_GELU;
@@ -154,20 +154,10 @@ int gemm8p_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_t 
     // evaluates erf while its partner's 16 MFMAs are long done -- and measured 2-3 % SLOWER than the unfolded epilogue, in
     // which both waves of a SIMD share the VALU (tools/bench_gemm.py --only enc --tiles 9 0: fc1 forward 830 vs 808 TFLOP/s)
     // round 5: bias + residual too (192-column tiles: proj / fc2 forward), the residual through registers (gemm8pp_impl.h)
-    // round 5b: * GELU'(saved pre-activation) as well (fc2 dgrad), on 192-column tiles whatever the width heuristic says: the
-    // side input in registers needs the 192-column configuration's register budget
+    // (* GELU'(saved pre-activation) through the same register loads was built and measured 7 % SLOWER than the one-tile kernel:
+    // its flush is VALU-bound on one wave per SIMD, profiles/r05_experiments.md (g))
     static const bool res_off = getenv("HTRVT_NO_PERSISTENT_RES") != nullptr && getenv("HTRVT_NO_PERSISTENT_RES")[0] == '1';
-    const bool side_epi = epi == E_RES || epi == E_GELUGRAD;
-    const void* sidep = epi == E_RES ? d->residual : d->preact;
-    bool res_ok = side_epi && !res_off && d->K >= 256 && (reinterpret_cast<unsigned long long>(sidep) & 3) == 0 && d->N % 12 == 0;
-    if (res_ok && bn != 192) {
-      if (epi == E_GELUGRAD && d->tile == 0 && zdim == 1 && d->batch <= 1 && d->K % 128 == 0) {
-        bn = 192;
-        p.tiles_n = (d->N + bn - 1) / bn;
-      } else {
-        res_ok = false;
-      }
-    }
+    const bool res_ok = epi == E_RES && bn == 192 && !res_off && d->K >= 256 && (reinterpret_cast<unsigned long long>(d->residual) & 3) == 0;
     const bool want = (d->tile >= 13 && d->tile <= 15) || (d->tile == 0 && !off && (epi == 0 || res_ok));
     if (want && (epi == 0 || epi == E_GELU || res_ok) && zdim == 1 && d->batch <= 1 && d->K % 128 == 0 && d->K >= 256 &&
         (reinterpret_cast<unsigned long long>(d->bias) & 15) == 0 && (d->preact == nullptr || (reinterpret_cast<unsigned long long>(d->preact) & 15) == 0)) {

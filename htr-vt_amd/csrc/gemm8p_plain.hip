@@ -29,7 +29,6 @@ int gemm8pp_dispatch_plain(int bn, int epi, const KParams& p, int nwg, hipStream
     if (epi == 0) return launch_persistent<Cfg<192, 4, 2>, 0>(p, nwg, st);
     if (epi == E_GELU) return launch_persistent<Cfg<192, 4, 2>, E_GELU>(p, nwg, st);
     if (epi == E_RES) return launch_persistent<Cfg<192, 4, 2>, E_RES>(p, nwg, st);
-    if (epi == E_GELUGRAD) return launch_persistent<Cfg<192, 4, 2>, E_GELUGRAD>(p, nwg, st);
   }
   return 0;
 }

@@ -226,8 +226,8 @@ constexpr int KT_SIDE = 4;       // last k-tile of a tile (E_RES): + the registe
 
 template <class C, int EPI, class P>
 __device__ __forceinline__ void gemm8pp_body(const P& p) {
-  static_assert(EPI == 0 || EPI == E_GELU || EPI == E_RES || EPI == E_GELUGRAD, "persistent kernel: bias / GELU / residual / GELU' epilogues");
-  constexpr bool RES = (EPI & (E_RES | E_GELUGRAD)) != 0;          // a side input per element (struct Side)
+  static_assert(EPI == 0 || EPI == E_GELU || EPI == E_RES, "persistent kernel: bias / GELU / residual epilogues");
+  constexpr bool RES = (EPI & E_RES) != 0;          // a side input per element (struct Side)
   constexpr int MT = C::MT, NT = C::NT, CW = 4 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 

@@ -253,6 +253,287 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
   gemm_epilogue<T, TM, TN, 1, BN, H::NTH, false>(acc, p, p.C, coff, mrow0, n0 + wn * TN * 32, 0, n0, 0, lane, smem, uok[un]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the same kernel on v_mfma_f32_16x16x32_bf16 with 96-channel units (gemm_hwgrad16_kernel<96, BN>).
+//
+// Layer 1 (192 channels) does not divide into the 128-channel chunks above: nine (kernel row, 64-channel chunk) units made
+// five PAIRED 384 x 192 tiles with the last one half empty (-10 %) and 5 x 48 K ranges filled 240 of 256 CUs (-6 %)
+// (1 019 TFLOP/s against 1 201-1 246 at layers 2-3).  With 96-channel chunks the 192 channels
+// are 3 x 2 = SIX full units of 288 x 192: 6 x 42 K ranges = 252 workgroups, nothing half empty.  A wave's 48 x 96 block is
+// 3 x 6 tiles of 16 x 16 (48 rows have no 32-row tiling): operands by two ds_read_b64_tr_b16 per 16 x 32 fragment -- the lane
+// groups of one read now take k-rows 8 g + q, so the LDS images are rotated by 32 bytes per 8 k-rows on top of the 64-byte
+// steps (X, 192-byte rows: 2 * ((r >> 3) & 1) chunks; dY, 384-byte rows: 4 * ((k >> 1) & 1) + 2 * ((k >> 3) & 1)) --
+// conflict-free by exhaustive check of the bank rule.  72 accumulators + two k-steps of fragments (one held across the
+// mid-tile barrier) fit the 168 registers of twelve waves; a 128-channel unit (96 accumulators) would not, so layers 2-3 stay
+// on the kernel above.  The chip also holds a higher clock on this MFMA shape (gemm_halo_impl.h).
+// ---------------------------------------------------------------------------------------------
+template <int CC, int BN>
+struct Hw16Geo {
+  static constexpr int NW = 12, NTH = NW * 64;
+  static constexpr int XROWB = CC * 2, XCPR = CC / 8;
+  static constexpr int XPIECES = (66 * XROWB + 1023) / 1024;   // 13 at CC = 96
+  static constexpr int XBYTES = XPIECES * 1024;
+  static constexpr int YROWB = BN * 2, YCPR = BN / 8;
+  static constexpr int YBYTES = 64 * YROWB, YPIECES = YBYTES / 1024;
+  static constexpr int STAGE = XBYTES + YBYTES, NSTAGE = 3, LDS_BYTES = NSTAGE * STAGE;
+  static constexpr int RT = CC / 32, CT = BN / 32;             // 16 x 16 tiles per wave: rows (CC / 2 channels), columns (BN / 2)
+  static constexpr int NPX = (XPIECES + NW - 1) / NW, NPY = YPIECES / NW;
+  static_assert((CC == 96 || CC == 128) && BN == 192 && YPIECES % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
+  // CC = 96: one k-step's fragments held across the mid-tile barrier (gemm_hwgrad_body); CC = 128 (96 accumulators): no room for
+  // that, the barrier sits between k-tiles
+  static constexpr bool HOLD = CC == 96;
+  static __device__ __forceinline__ int xrot(int r) { return CC == 96 ? 2 * ((r >> 3) & 1) : 4 * (r & 3) + 2 * ((r >> 3) & 1); }
+  static __device__ __forceinline__ int yrot(int k) { return BN == 192 ? 4 * ((k >> 1) & 1) + 2 * ((k >> 3) & 1) : 4 * (k & 3) + 2 * ((k >> 3) & 1); }
+};
+
+typedef float f32x4w_t __attribute__((ext_vector_type(4)));
+
+template <int CC, int BN, class P>
+__device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x) {
+  using H = Hw16Geo<CC, BN>;
+  constexpr int NW = H::NW, RT = H::RT, CT = H::CT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int NCC = p.Cpad / CC;                       // chunks per kernel row
+  const int nunits = 3 * NCC;
+  const int ntiles = nunits * p.tiles_n;
+  int id = block_x, z = blockIdx.z;
+  if (p.split_k > 1 && (p.split_k & 7) == 0) {       // all tiles of one pixel range on one XCD (they read the same x / dY rows)
+    const int chunk = block_x / (8 * ntiles), r = block_x - chunk * 8 * ntiles;
+    z = chunk * 8 + (r & 7);
+    id = r >> 3;
+  }
+  const int tm = id / p.tiles_n, tile_n = id - tm * p.tiles_n;
+  const int dyu = tm / NCC, ciu = (tm - dyu * NCC) * CC;
+  const int n0 = tile_n * BN;
+  int kbeg = 0, kend = p.K;
+  long long coff = 0;
+  if (p.split_k > 1) {
+    kbeg = z * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+    coff = (long long)z * p.slab_stride;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;           // 6 x 2
+  const int dx = wm >> 1;                            // two waves per tap, CC / 2 channels each
+  const int crow = (wm & 1) * (CC / 2);
+
+  // ---- DMA bookkeeping: per piece (row / k-row, source chunk) of this lane, formed once ----
+  const unsigned long long xa = (unsigned long long)p.A, ya = (unsigned long long)p.B;
+  const i32x4_t rsrcX = i32x4_t{(int)(unsigned)(xa & 0xffffffffull), (int)(unsigned)((xa >> 32) & 0xffffull), (int)OOB, 0x00020000};
+  const i32x4_t rsrcY = i32x4_t{(int)(unsigned)(ya & 0xffffffffull), (int)(unsigned)((ya >> 32) & 0xffffull), (int)OOB, 0x00020000};
+  int xr[H::NPX], xc[H::NPX];
+  bool xok[H::NPX];
+#pragma unroll
+  for (int i = 0; i < H::NPX; ++i) {
+    const int pi = wave + NW * i;
+    const int q = pi * 1024 + lane * 16;
+    const int r = q / H::XROWB, cd = (q - r * H::XROWB) >> 4;
+    int cs = cd - H::xrot(r);
+    cs += cs < 0 ? H::XCPR : 0;
+    xr[i] = r;
+    xc[i] = cs;
+    xok[i] = pi < H::XPIECES && r < 66 && ciu + cs * 8 < p.Ci;
+  }
+  unsigned yoff[H::NPY];
+  int ykr[H::NPY];
+#pragma unroll
+  for (int i = 0; i < H::NPY; ++i) {
+    const int sidx = (wave + NW * i) * 64 + lane;
+    const int kr = sidx / H::YCPR, cl = sidx - kr * H::YCPR;
+    int cg = cl - H::yrot(kr);
+    cg += cg < 0 ? H::YCPR : 0;
+    const int col = n0 + cg * 8;
+    ykr[i] = kr;
+    yoff[i] = col < p.N ? (unsigned)kr * (unsigned)(p.ldb * 2) + (unsigned)col * 2u : OOB;
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  const int Hh = p.Hi, Ww = p.Wi;
+  int iq_row = kbeg / Ww, iq_w0 = kbeg - iq_row * Ww, iq_k = kbeg;
+  auto issue = [&](int stage) {
+    const unsigned sbase = lds0 + stage * H::STAGE;
+    const int bimg = iq_row / p.Ho, hrow = iq_row - bimg * p.Ho;
+    const int hh = hrow * p.sh + dyu - 1;
+    const bool rowok = iq_k < kend && (unsigned)hh < (unsigned)Hh;
+    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + iq_w0 - 1) * p.Ci + ciu) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+#pragma unroll
+    for (int i = 0; i < H::NPX; ++i) {
+      if (wave + NW * i < H::XPIECES) {      // wave-uniform
+        const int w = iq_w0 - 1 + xr[i];
+        const bool v = rowok && xok[i] && (unsigned)w < (unsigned)Ww;
+        const unsigned voff = v ? gbase + (unsigned)(xr[i] * p.Ci + xc[i] * 8) * 2u : OOB;
+        dma16(rsrcX, __builtin_amdgcn_readfirstlane(sbase + (wave + NW * i) * 1024), voff);
+      }
+    }
+    const unsigned ybase = (unsigned)iq_k * (unsigned)(p.ldb * 2);
+#pragma unroll
+    for (int i = 0; i < H::NPY; ++i) {
+      const bool v = yoff[i] < OOB && iq_k + ykr[i] < kend;
+      dma16(rsrcY, __builtin_amdgcn_readfirstlane(sbase + H::XBYTES + (wave + NW * i) * 1024), v ? ybase + yoff[i] : OOB);
+    }
+    iq_k += BK;
+    iq_w0 += BK;
+    if (iq_w0 >= Ww) {
+      iq_w0 = 0;
+      ++iq_row;
+    }
+  };
+
+  f32x4w_t acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = f32x4w_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  issue(0);
+  issue(1);
+  // this wave's pieces of tile 0 have landed, tile 1 may fly (per-wave piece count: NPY + 1 or 2 X pieces)
+  if (wave + NW * (H::NPX - 1) < H::XPIECES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NPX + H::NPY) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NPX - 1 + H::NPY) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // 16 x 32 operand fragments by two transposed reads: lane (g, q, pp) supplies k-row 8 g + q (then + 4), columns 4 pp .. 4 pp + 3 of the
+  // tile's 16; it receives column (lane & 15), k = 8 g .. 8 g + 7
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  typedef __attribute__((address_space(3))) s16x4_t* lptr;
+  auto xfrag = [&](const char* xs, int i, int s) {
+    const int r0 = 32 * s + 8 * g + q + dx;
+    const int cb = (crow + 16 * i) / 8 + (pp >> 1);
+    int c0 = cb + H::xrot(r0), c1 = cb + H::xrot(r0 + 4);
+    c0 -= c0 >= H::XCPR ? H::XCPR : 0;
+    c1 -= c1 >= H::XCPR ? H::XCPR : 0;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + r0 * H::XROWB + c0 * 16 + (pp & 1) * 8));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + (r0 + 4) * H::XROWB + c1 * 16 + (pp & 1) * 8));
+    const s16x8_t r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+  auto yfrag = [&](const char* ys, int j, int s) {
+    const int k0 = 32 * s + 8 * g + q;
+    const int cb = (wn * (BN / 2) + 16 * j) / 8 + (pp >> 1);
+    int c0 = cb + H::yrot(k0), c1 = cb + H::yrot(k0 + 4);
+    c0 -= c0 >= H::YCPR ? H::YCPR : 0;
+    c1 -= c1 >= H::YCPR ? H::YCPR : 0;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ys + k0 * H::YROWB + c0 * 16 + (pp & 1) * 8));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(ys + (k0 + 4) * H::YROWB + c1 * 16 + (pp & 1) * 8));
+    const s16x8_t r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+  auto kstep_load = [&](const char* xs, const char* ys, int s, bf16x8_t (&fa)[RT], bf16x8_t (&fb)[CT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) fa[i] = xfrag(xs, i, s);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) fb[j] = yfrag(ys, j, s);
+  };
+  auto kstep_mma = [&](const bf16x8_t (&fa)[RT], const bf16x8_t (&fb)[CT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+  if constexpr (H::HOLD) {
+  // one barrier per k-tile, between its two k-steps (see gemm_hwgrad_body): the fragments of step 1 are requested before it
+  bf16x8_t fa2[RT], fb2[CT];
+  if (nkt > 0) {
+    bf16x8_t fa[RT], fb[CT];
+    kstep_load(smem, smem + H::XBYTES, 0, fa, fb);
+    kstep_mma(fa, fb);
+    kstep_load(smem, smem + H::XBYTES, 1, fa2, fb2);
+  }
+  int cur = 0, nxt = 2;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt + 1
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);            // k-tile kt + 2 (zero fill past the range) into the stage of tile kt - 1
+    kstep_mma(fa2, fb2);
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
+    if (kt + 1 < nkt) {    // first half of the next tile: complete since the barrier above
+      const char* xn = smem + cur * H::STAGE;
+      const char* yn = xn + H::XBYTES;
+      bf16x8_t fa[RT], fb[CT];
+      kstep_load(xn, yn, 0, fa, fb);
+      kstep_mma(fa, fb);
+      kstep_load(xn, yn, 1, fa2, fb2);
+    }
+  }
+  } else {
+  // barrier between k-tiles: tile kt + 1 landed (own pieces waited for) before it, tile kt + 2 issued behind it
+  int cur = 0, nxt = 2;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* xs = smem + cur * H::STAGE;
+    const char* ys = xs + H::XBYTES;
+    if (kt > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    issue(nxt);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t fa[RT], fb[CT];
+      kstep_load(xs, ys, s2, fa, fb);
+      kstep_mma(fa, fb);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
+  }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: rows of the packed weight gradient [tap][Cpad][Co]: m = (dy * 3 + dx) * Cpad + first channel of the unit + channel ----
+  // acc[i][j][r] = C(channel crow + 16 i + 4 g + r, column wn * BN / 2 + 16 j + (lane & 15)); float32, plain stores into the K range's slab
+  // or atomic accumulation (HtrvtGemmDesc.accumulate without splitk_ws)
+  float* Cf = reinterpret_cast<float*>(p.C) + coff;
+  const int mbase = (dyu * 3 + dx) * p.Cpad + ciu + crow + 4 * g;
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int n = n0 + wn * (BN / 2) + 16 * j + (lane & 15);
+      if (n < p.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = Cf + (long long)(mbase + 16 * i + r) * p.ldc + n;
+          const float v = acc[i][j][r] * p.alpha;
+          if (p.accumulate) atomicAdd(dst, v);
+          else *dst = v;
+        }
+      }
+    }
+}
+
+template <int CC, int BN>
+__global__ __launch_bounds__(768) void gemm_hwgrad16_kernel(const KParams p) {
+  typedef const __attribute__((address_space(4))) KParams KP;
+  (void)p;
+  KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+  gemm_hwgrad16_body<CC, BN>(*kp, (int)blockIdx.x);
+}
+
+template <int CC, int BN>
+int launch_hwgrad16(const KParams& p, int zdim, hipStream_t st) {
+  using H = Hw16Geo<CC, BN>;
+  static bool attr_done = false;
+  auto kern = gemm_hwgrad16_kernel<CC, BN>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(%d B LDS): %s", H::LDS_BYTES, hipGetErrorString(e));
+      return -2;
+    }
+    attr_done = true;
+  }
+  const int ntiles = 3 * (p.Cpad / CC) * p.tiles_n;
+  dim3 grid(ntiles, 1, zdim);
+  if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
+  set_last_kernel("gemm_hwgrad16_kernel<%d, %d>", CC, BN);
+  const int rc = check_launch("gemm_hwgrad16_kernel");
+  return rc ? rc : 1;
+}
+
 template <int CC, int BN, bool PAIR = false>
 __global__ __launch_bounds__(768) void gemm_hwgrad_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;

@@ -202,7 +202,7 @@ def test_halo_conv_row_stride_forward_wgrad_exact(cfg):
         ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
                  gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, tile=tile)
         if tile == 13:
-            assert "gemm_hwgrad_kernel" in _last_kernel(), _last_kernel()
+            assert "gemm_hwgrad" in _last_kernel(), _last_kernel()
         assert torch.equal(dwp.double().cpu(), base + want), (tile, split_k, float((dwp.double().cpu() - base - want).abs().max()))
 
 
@@ -332,6 +332,7 @@ HWGRAD = [  # B, H, W, Ci, Co, split_k
     (1, 2, 256, 768, 768, 1),      # no split at all
     (3, 2, 64, 96, 256, 5),        # Ci = 96 -> Cpad 128 with a quarter padding; Co = 256 -> 128-column tiles; W = 64
     (2, 8, 192, 64, 64, 16),       # Ci = Co = 64: one chunk, half-empty 128-column tile
+    (1, 3, 192, 160, 192, 3),      # Ci = 160 -> Cpad 192: 96-channel units (16x16x32 kernel) with padded channels, plain split, W = 192
 ]
 
 
@@ -351,14 +352,17 @@ def test_halo_conv_wgrad_exact(cfg, slabs):
     xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
     want = T._pack_fwd(w.grad, cpi).permute(1, 2, 0)            # [taps][Cpad][Co]
-    for tile in (13, 3):                                         # 13: halo kernel, 3: the generic MN-major gather
+    tiles = (13, 3) + ((18,) if cpi % 128 else ())              # 13: halo kernel (Cpad 192: the 16x16x32 form), 3: the generic MN-major gather, 18: the paired 32x32x16 form
+    for tile in tiles:
         base = T._ints((9, cpi, Co), -5, 6, seed=73)
         dwp = base.float().cuda()
         ws = torch.empty(max(split_k, 1), 9 * cpi, Co, dtype=torch.float32, device="cuda") if (slabs and split_k > 1) else None
         ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
                  gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, splitk_ws=ws, tile=tile)
-        if tile == 13:
-            assert "gemm_hwgrad_kernel" in _last_kernel(), _last_kernel()
+        if tile in (13, 18):
+            assert "gemm_hwgrad" in _last_kernel(), _last_kernel()
+        if tile == 13 and cpi % 128 and cpi % 96 == 0 and Co > 128:
+            assert "gemm_hwgrad16_kernel" in _last_kernel(), _last_kernel()
         assert torch.equal(dwp.double().cpu(), base + want), (tile, float((dwp.double().cpu() - base - want).abs().max()))
 
 

@@ -130,7 +130,7 @@ def main():
         split17 = eng_._split_k(g.taps * Ci, Co, M, conv=True, tiling=(3 * (Ci // 64) * ((Co + 191) // 192), 192, 192))   # tile 17: unpaired 64-channel tiles
         ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
                                      b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci,
-                                     split_k=split_h if TILE in (0, 13) else (split17 if TILE == 17 else split), accumulate=True, c_f32=True), args.iters)
+                                     split_k=split_h if TILE in (0, 13, 18, 19) else (split17 if TILE == 17 else split), accumulate=True, c_f32=True), args.iters)
         rows.append((tag + f" wgrad(split {split_h}/{split})", ms, fl))
 
     if not args.only or "plain" in args.only:

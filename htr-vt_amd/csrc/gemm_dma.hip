@@ -13,6 +13,7 @@ int gemm_dma_dispatch_bn128_s3(const HtrvtGemmDesc*, const KParams&, int, hipStr
 int gemm_dma_dispatch_bn192(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_dma_dispatch_bn256(const HtrvtGemmDesc*, const KParams&, int, hipStream_t, bool);
 int gemm_halo_try_launch(const HtrvtGemmDesc*, const KParams&, int bn, hipStream_t);
+int gemm_halo_fs2_try_launch(const HtrvtGemmDesc*, const KParams&, int bn, hipStream_t);
 int gemm_hwgrad_try_launch(const HtrvtGemmDesc*, KParams&, int zdim, hipStream_t);
 int gemm_halo_s2_try_launch(const HtrvtGemmDesc*, KParams&, hipStream_t, bool probe);
 int conv1x1_try_launch(const HtrvtGemmDesc*, KParams&, hipStream_t);
@@ -124,6 +125,8 @@ int gemm_dma_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStream_
   if (bn == 192 || bn == 128) {   // 3x3 stride-1 convolutions whose M tiles are row segments: halo-staged A operand (gemm_halo_impl.h)
     const int r = gemm_halo_try_launch(d, p, bn, st);
     if (r != 0) return r;
+    const int r2 = gemm_halo_fs2_try_launch(d, p, bn, st);   // column stride 2: odd / even pixel images
+    if (r2 != 0) return r2;
   }
   const bool spec = use_loader_waves(d);
   if (bn == 256) return gemm_dma_dispatch_bn256(d, p, zdim, st, false);

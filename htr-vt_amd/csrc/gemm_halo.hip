@@ -26,6 +26,22 @@ int gemm_halo_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipSt
   return 0;
 }
 
+// Forward with a column stride of 2 (layer2.0 / layer3.0 conv1, stride (2,2)): odd / even pixel images (gemm_halo_fs2_kernel).
+// Same return convention and caller-set tiling as gemm_halo_try_launch.
+int gemm_halo_fs2_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipStream_t st) {
+  if (d->gather != HTRVT_GATHER_CONV_FWD || d->dtype != HTRVT_BF16) return 0;
+  if (d->tile != 0 && d->tile != 4 && d->tile != 12) return 0;      // 5: the generic gather (A/B)
+  if (d->kh != 3 || d->kw != 3 || d->sw != 2 || (d->sh != 1 && d->sh != 2) || d->ph != 1 || d->pw != 1 || d->cls_h >= 0) return 0;
+  if ((d->Wi & 1) || d->Wo != d->Wi / 2 || d->Ho != (d->Hi - 1) / d->sh + 1 || (d->Wo % 256) != 0) return 0;   // an M tile = 256 pixels of one output row
+  if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->c_f32 || d->M != d->nB * d->Ho * d->Wo) return 0;
+  if ((d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;   // the staged bf16 epilogue
+  if (d->preact != nullptr || (d->act != 0 && d->act != 3)) return 0;
+  if (d->residual != nullptr && d->colscale == nullptr) return 0;    // a residual only as part of the eval fold
+  if (bn == 192) return launch_halo_fs2<192>(p, st);
+  if (bn == 128) return launch_halo_fs2<128>(p, st);
+  return 0;
+}
+
 
 // Merged strided dgrad (HtrvtGemmDesc.cls_h == -2): 1 launched, 0 not served, < 0 error.  Sets p.tiles_m / tiles_n / Hq / Wq.
 // `probe`: only answer (tiles_m, or 0) -- htrvt_gemm_dgrad_merged_tiles

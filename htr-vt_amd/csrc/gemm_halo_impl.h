@@ -483,6 +483,183 @@ int launch_halo_s2(const KParams& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 pad-1 convolution FORWARD with a COLUMN stride of 2 on halo-staged tiles (resnet18.py:26: conv1 of layer2.0 / layer3.0,
+// stride (2,2); round 5 -- these launches ran on the generic per-row gather until now).
+//
+// Output pixel (ho, wo) reads x(ho sh + dy - 1, 2 wo + dx - 1).  An M tile is 256 consecutive output pixels wo0 .. wo0 + 255 of
+// one output row: its column taps dx = 0 and dx = 2 read the ODD input pixels 2 wo0 - 1, 2 wo0 + 1, ... (dx = 2 the same
+// pixels as dx = 0, one tile row further down) and dx = 1 the EVEN pixels 2 wo0, 2 wo0 + 2, ...  Per (kernel row, 64-channel
+// chunk) = "unit": ONE odd image of 257 pixels serves two k-tiles (row shift 0 / 1) and one even image of 256 pixels the third
+// -- 36 + 32 DMA pieces instead of 3 x 32, and the loader waves form one address per piece instead of decoding a pixel per
+// row and tap.  k-tile order inside a unit: dx = 0, dx = 2 (odd image, LDS stage X), dx = 1 (even image, stage Y).  B runs
+// two k-tiles ahead through three stages as in gemm_halo_body; the even image of a unit is issued during the unit's first
+// k-tile and has two k-tiles to land; the odd image of the NEXT unit can only be issued when the current unit's second
+// k-tile has read stage X for the last time, i.e. during the third k-tile, and must land within it (a second odd stage
+// would need 170 KB with three B stages).
+// ---------------------------------------------------------------------------------------------
+template <int BN>
+struct HaloFs2Geo {
+  static constexpr int NPO = 9, NPE = 8;                  // 1-KiB pieces per loader wave: odd image (288 rows, 257 used), even image (256 rows)
+  static constexpr int X_BYTES = 4 * NPO * 1024, Y_BYTES = 4 * NPE * 1024;
+  static constexpr int B_STAGE = Geo<BN>::BYTES;
+  static constexpr int NP_B = B_STAGE / 1024 / 4;
+  static constexpr unsigned Y_BASE = X_BYTES, B_BASE = X_BYTES + Y_BYTES;
+  static constexpr int LDS_BYTES = X_BYTES + Y_BYTES + 3 * B_STAGE;
+  static_assert(B_STAGE % 4096 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(LDS_BYTES >= BN * Stg<256>::CST, "the staged epilogue's column-major image");
+};
+
+template <int BN, class P>
+__device__ __forceinline__ void gemm_halo_fs2_body(const P& p, const int block_x) {
+  using H = HaloFs2Geo<BN>;
+  constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = block_x;
+  if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int rowo = m0 / p.Wo, wo0 = m0 - rowo * p.Wo;     // output row (b * Ho + ho), first output column of this tile
+  const int bimg = rowo / p.Ho, ho = rowo - bimg * p.Ho;
+  const int NC = p.Cpad / BK;
+  const int NU = 3 * NC;                                  // units = (kernel row, chunk); k-tiles = 3 NU
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (wave >> 1) & 3, wn = wave & 1;
+
+  if (wave < NWC) {
+    // ================================ consumer waves ================================
+    f32x4h_t a4[2 * TM][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();
+    for (int u = 0; u < NU; ++u) {
+      halo_mma16<BN, TM, TN>(a4, smem, smem + H::B_BASE + 0 * H::B_STAGE, 0, wm, wn, lane);               // dx = 0
+      __builtin_amdgcn_s_barrier();
+      halo_mma16<BN, TM, TN>(a4, smem, smem + H::B_BASE + 1 * H::B_STAGE, 1, wm, wn, lane);               // dx = 2
+      __builtin_amdgcn_s_barrier();
+      halo_mma16<BN, TM, TN>(a4, smem + H::Y_BASE, smem + H::B_BASE + 2 * H::B_STAGE, 0, wm, wn, lane);   // dx = 1
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+    halo_acc16_to_32<TM, TN>(acc, a4);
+    epilogue_staged<TN, BN, BM, NW_TOTAL, false, true, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+  } else {
+    // ================================ loader waves ================================
+    const int lw = (wave - NWC) & 3;
+    __builtin_amdgcn_s_setprio(3);
+    DmaLoader<BN, HTRVT_KMAJOR, 0, 4> lb;
+    lb.init(p, p.B, p.ldb, n0, p.N, lw, lane);
+    const unsigned long long ba = (unsigned long long)p.A;
+    const i32x4_t rsrcA = i32x4_t{(int)(unsigned)(ba & 0xffffffffull), (int)(unsigned)((ba >> 32) & 0xffffull), (int)OOB, 0x00020000};
+    const int Hh = p.Hi, Ww = p.Wi, Cs = p.Ci;
+    const int rho0 = lw * 8 + (lane >> 3);                // this lane's image row in piece lw; piece lw + 4 i is 32 i rows further down
+    const int cgA = (lane & 7) ^ Geo<BM>::swz(rho0);
+    const int wsrc0 = 2 * (wo0 + rho0) - 1;               // source pixel of odd-image row rho0 (even image: + 1); 32 image rows = 64 pixels
+    const unsigned lane_off = (unsigned)(wsrc0 * Cs + cgA * 8) * 2u;   // may wrap for wsrc0 < 0: masked below
+    const unsigned lds0 = lds_addr_of(smem);
+    // image `par` (0 odd -> stage X, 1 even -> stage Y) of unit (udy, ucc); uvalid false: zero fill
+    auto issueA = [&](int par, int udy, int ucc, bool uvalid) {
+      const int hh = ho * p.sh + udy - 1;
+      const bool rowok = uvalid && (unsigned)hh < (unsigned)Hh;
+      const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + par) * Cs + ucc * BK) * 2u;
+      const bool chok = ucc * BK + cgA * 8 < Cs;
+      if (par == 0) {
+#pragma unroll
+        for (int i = 0; i < H::NPO; ++i) {
+          const int rho = rho0 + 32 * i, w = wsrc0 + 64 * i;
+          const bool v = rowok && chok && rho < 257 && (unsigned)w < (unsigned)Ww;
+          dma16(rsrcA, __builtin_amdgcn_readfirstlane(lds0 + (lw + 4 * i) * 1024), v ? gbase + lane_off + (unsigned)(64 * i * Cs) * 2u : OOB);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < H::NPE; ++i) {
+          const int w = wsrc0 + 1 + 64 * i;
+          const bool v = rowok && chok && (unsigned)w < (unsigned)Ww;
+          dma16(rsrcA, __builtin_amdgcn_readfirstlane(lds0 + H::Y_BASE + (lw + 4 * i) * 1024), v ? gbase + lane_off + (unsigned)(64 * i * Cs) * 2u : OOB);
+        }
+      }
+    };
+    auto issueB = [&](int bst, int udy, int ucc, int dx, bool uvalid) {
+      lb.template issue<true>(p, lds0 + H::B_BASE + bst * H::B_STAGE, uvalid ? (udy * 3 + dx) * p.Cpad + ucc * BK : p.K, p.K, lw);
+    };
+    // ---- prologue: odd image of unit 0, B of k-tiles 0 (dx = 0) and 1 (dx = 2) ----
+    issueA(0, 0, 0, true);
+    issueB(0, 0, 0, 0, true);
+    issueB(1, 0, 0, 2, true);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int udy = 0, ucc = 0;
+    for (int u = 0; u < NU; ++u) {
+      int ndy = udy, ncc = ucc + 1;
+      if (ncc == NC) {
+        ncc = 0;
+        ++ndy;
+      }
+      const bool nvalid = u + 1 < NU;
+      // k-tile 3u (dx = 0): B of this unit's third k-tile; its even image (two k-tiles to land)
+      issueB(2, udy, ucc, 1, true);
+      issueA(1, udy, ucc, true);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B + H::NPE) : "memory");
+      __builtin_amdgcn_s_barrier();
+      // k-tile 3u + 1 (dx = 2): B of the next unit's first k-tile; the even image has landed behind this wait
+      issueB(0, ndy, ncc, 0, nvalid);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+      __builtin_amdgcn_s_barrier();
+      // k-tile 3u + 2 (dx = 1): stage X is free -- the next unit's odd image, then B of its second k-tile
+      issueA(0, ndy, ncc, nvalid);
+      issueB(1, ndy, ncc, 2, nvalid);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H::NP_B) : "memory");
+      __builtin_amdgcn_s_barrier();
+      udy = ndy;
+      ucc = ncc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill pieces issued past the last k-tile
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    epilogue_staged<TN, BN, BM, NW_TOTAL, false, true, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, false);
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(768) void gemm_halo_fs2_kernel(const KParams p) {
+  typedef const __attribute__((address_space(4))) KParams KP;
+  (void)p;
+  KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
+  gemm_halo_fs2_body<BN>(*kp, (int)blockIdx.x);
+}
+
+template <int BN>
+int launch_halo_fs2(const KParams& p, hipStream_t st) {
+  constexpr int LDS = HaloFs2Geo<BN>::LDS_BYTES;
+  static bool attr_done = false;
+  auto kern = gemm_halo_fs2_kernel<BN>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
+      return -2;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), LDS, st, p);
+  set_last_kernel("gemm_halo_fs2_kernel<%d>", BN);
+  const int rc = check_launch("gemm_halo_fs2_kernel");
+  return rc ? rc : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_halo_body, round 5: consumer and loader waves run SEPARATE copies of the loop (same barriers) -- straight-line fragment
 // reads + MFMAs between barriers on one side, nothing but address arithmetic and DMA issue on the other.  In the one-loop form
 // above every wave walked both sides' branches and the register allocation, the scalar state and the instruction stream of

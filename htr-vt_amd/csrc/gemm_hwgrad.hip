@@ -9,13 +9,13 @@ namespace htrvt {
 // round 5: a padded channel count that is a multiple of 96 but not of 128 (layer 1: 192) takes 96-channel units on the 16x16x32
 // kernel (gemm_hwgrad16_kernel: 288 x 192 tiles, no half-empty pair); tile 18 asks for the paired form of round 4 (A/B)
 int gemm_hwgrad_bn(const HtrvtGemmDesc* d);
-// tile 19 (A/B): the 16x16x32 kernel with 128-channel units where they divide Cpad (layers 2-3)
+// (the 16x16x32 kernel with 128-channel units at layers 2-3 -- 96 accumulators + two k-steps of fragments, 25 registers in scratch --
+// measured EQUAL to the 32x32x16 kernel there: 0.584 / 0.572 against 0.587 / 0.572 ms, profiles/r05_experiments.md (i); not kept)
 bool gemm_hwgrad_is16(const HtrvtGemmDesc* d) {
   if (gemm_hwgrad_bn(d) != 192) return false;
-  if (d->tile == 19) return d->Cpad % 128 == 0;
   return d->Cpad % 128 != 0 && d->Cpad % 96 == 0 && (d->tile == 0 || d->tile == 13);
 }
-int gemm_hwgrad_cc(const HtrvtGemmDesc* d) { return gemm_hwgrad_is16(d) ? (d->tile == 19 ? 128 : 96) : ((d->Cpad % 128 == 0 || d->tile != 17) ? 128 : 64); }
+int gemm_hwgrad_cc(const HtrvtGemmDesc* d) { return gemm_hwgrad_is16(d) ? 96 : ((d->Cpad % 128 == 0 || d->tile != 17) ? 128 : 64); }
 bool gemm_hwgrad_pair(const HtrvtGemmDesc* d) { return !gemm_hwgrad_is16(d) && d->Cpad % 128 != 0 && d->tile != 17; }
 int gemm_hwgrad_bn(const HtrvtGemmDesc* d) {
   const int p192 = (d->N + 191) / 192 * 192, p128 = (d->N + 127) / 128 * 128;
@@ -24,7 +24,7 @@ int gemm_hwgrad_bn(const HtrvtGemmDesc* d) {
 
 bool gemm_hwgrad_serves(const HtrvtGemmDesc* d) {
   if (d->gather != HTRVT_GATHER_CONV_WGRAD || d->dtype != HTRVT_BF16) return false;
-  if (d->tile != 0 && d->tile != 13 && d->tile != 17 && d->tile != 18 && d->tile != 19) return false;      // 13: this kernel where eligible (17: without unit pairing); 3 / 4 / 6: the generic kernels (A/B)
+  if (d->tile != 0 && d->tile != 13 && d->tile != 17 && d->tile != 18) return false;      // 13: this kernel where eligible (17: without unit pairing); 3 / 4 / 6: the generic kernels (A/B)
   if (d->kh != 3 || d->kw != 3 || (d->sh != 1 && d->sh != 2) || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;   // row stride 2: layer1.0.conv1
   if (d->Ho != (d->Hi - 1) / d->sh + 1 || d->Wo != d->Wi || (d->Wi % 64) != 0) return false;     // a k-tile = 64 pixels of one image row
   if (!d->c_f32 || d->batch > 1 || d->Cpad % 64 != 0 || d->M != 9 * d->Cpad || d->N != d->Co) return false;
@@ -46,7 +46,7 @@ int gemm_hwgrad_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStre
   p.tiles_n = (d->N + bn - 1) / bn;
   if (gemm_hwgrad_is16(d)) {
     p.tiles_m = 3 * (d->Cpad / cc);
-    return cc == 96 ? launch_hwgrad16<96, 192>(p, zdim, st) : launch_hwgrad16<128, 192>(p, zdim, st);
+    return launch_hwgrad16<96, 192>(p, zdim, st);
   }
   if (gemm_hwgrad_pair(d)) {
     p.tiles_m = (3 * (d->Cpad / 64) + 1) / 2;

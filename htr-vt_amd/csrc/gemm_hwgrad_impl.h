@@ -278,7 +278,7 @@ struct Hw16Geo {
   static constexpr int STAGE = XBYTES + YBYTES, NSTAGE = 3, LDS_BYTES = NSTAGE * STAGE;
   static constexpr int RT = CC / 32, CT = BN / 32;             // 16 x 16 tiles per wave: rows (CC / 2 channels), columns (BN / 2)
   static constexpr int NPX = (XPIECES + NW - 1) / NW, NPY = YPIECES / NW;
-  static_assert((CC == 96 || CC == 128) && BN == 192 && YPIECES % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
+  static_assert(CC == 96 && BN == 192 && YPIECES % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
   // CC = 96: one k-step's fragments held across the mid-tile barrier (gemm_hwgrad_body); CC = 128 (96 accumulators): no room for
   // that, the barrier sits between k-tiles
   static constexpr bool HOLD = CC == 96;

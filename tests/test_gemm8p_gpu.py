@@ -207,6 +207,52 @@ def test_halo_conv_row_stride_forward_wgrad_exact(cfg):
 
 
 
+HALO_COLSTRIDE = [  # B, H, W, Ci, Co, stride: conv1 of layer2.0 / layer3.0 (stride (2,2)) on odd / even pixel images (gemm_halo_fs2_kernel)
+    (2, 8, 1024, 192, 384, (2, 2)),    # two tiles per output row (the odd image's first pixel inside the image for the second), 3 chunks, two 192-column tiles
+    (3, 5, 512, 64, 128, (2, 2)),      # odd H: the last output row's third kernel row is padding; 128-column tile; one chunk
+    (1, 1, 512, 96, 256, (2, 2)),      # H = 1: kernel rows 0 and 2 outside the image; Cpad 128 with a half-padded chunk; 128-column tiles
+    (2, 3, 512, 128, 192, (1, 2)),     # row stride 1 with a column stride of 2
+]
+
+
+@pytest.mark.parametrize("cfg", HALO_COLSTRIDE)
+def test_halo_conv_col_stride_forward_exact(cfg):
+    """the column-strided 3x3 forward against torch's float64 convolution on integer data: raw output + BatchNorm column sums
+    (training) and the eval-mode fold, the generic gather (tile 5) beside it"""
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co, stride = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=90)
+    w = T._ints((Co, Ci, 3, 3), -2, 3, seed=91)
+    y = F.conv2d(x, w, None, stride=stride, padding=1)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, stride, 1)
+    assert (geom.Ho, geom.Wo) == tuple(y.shape[2:])
+    M = Bn * geom.Ho * geom.Wo
+    cpi = ops.cpad(Ci, BF)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wf = T._pack_fwd(w, cpi).to(BF).cuda()
+    y_nhwc = y.permute(0, 2, 3, 1)
+    for tile in (12, 5):
+        yd = torch.full((Bn, geom.Ho, geom.Wo, Co), 9.0, dtype=BF, device="cuda")
+        nmt = ops.gemm_num_mtiles(M, Co, BF, gather=ops.GATHER_CONV_FWD)
+        cs = torch.zeros(nmt, 2, Co, dtype=torch.float32, device="cuda")
+        ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+                 Cpad=cpi, colstats=cs, tile=tile)
+        if tile == 12:
+            assert "gemm_halo_fs2_kernel" in _last_kernel(), _last_kernel()
+        assert torch.equal(yd.double().cpu(), y_nhwc.to(BF).double()), (tile, _last_kernel(), float((yd.double().cpu() - y_nhwc).abs().max()))
+        assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
+        assert torch.allclose(cs[:, 1].sum(0).double().cpu(), (y_nhwc.reshape(-1, Co) ** 2).sum(0), rtol=1e-6, atol=1e-3)
+    g = torch.Generator().manual_seed(92)
+    scale = torch.tensor([0.25, 0.5, 1.0, -0.5])[torch.randint(0, 4, (Co,), generator=g)].double()
+    shift = torch.randint(-8, 9, (Co,), generator=g).double()
+    ref = (y_nhwc * scale + shift).clamp_min(0.0)
+    yd = torch.full((Bn, geom.Ho, geom.Wo, Co), 9.0, dtype=BF, device="cuda")
+    ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+             Cpad=cpi, colscale=scale.float().cuda(), bias=shift.float().cuda(), act=3, tile=12)
+    assert "gemm_halo_fs2_kernel" in _last_kernel(), _last_kernel()
+    assert torch.equal(yd.double().cpu(), ref.to(BF).double()), _last_kernel()
+
+
 @pytest.mark.parametrize("cfg", HALO)
 def test_halo_conv_forward_dgrad_exact(cfg):
     ops = T._ops()

@@ -208,6 +208,9 @@ def main():
         conv("l2 384->384 s1 [128,4,512]", 128, 4, 512, 384, 384, 3, (1, 1), 1)
         conv("l3 768->768 s1 [128,2,256]", 128, 2, 256, 768, 768, 3, (1, 1), 1)
         conv("l2.0 192->384 s2 [128,8,1024]", 128, 8, 1024, 192, 384, 3, (2, 2), 1)
+    if "sconv" in args.only:       # the two stride-(2,2) 3x3 convolutions of the stem (conv1 of layer2.0 / layer3.0)
+        conv("l2.0 192->384 s2 [128,8,1024]", 128, 8, 1024, 192, 384, 3, (2, 2), 1)
+        conv("l3.0 384->768 s2 [128,4,512]", 128, 4, 512, 384, 768, 3, (2, 2), 1)
     if "c1x1" in args.only:        # the three 1x1 strided downsample convolutions of the stem
         conv("l1.0 ds 192->192 s(2,1) [128,16,1024]", 128, 16, 1024, 192, 192, 1, (2, 1), 0)
         conv("l2.0 ds 192->384 s(2,2) [128,8,1024]", 128, 8, 1024, 192, 384, 1, (2, 2), 0)

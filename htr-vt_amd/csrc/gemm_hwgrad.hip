@@ -13,6 +13,10 @@ int gemm_hwgrad_bn(const HtrvtGemmDesc* d);
 // measured EQUAL to the 32x32x16 kernel there: 0.584 / 0.572 against 0.587 / 0.572 ms, profiles/r05_experiments.md (i); not kept)
 bool gemm_hwgrad_is16(const HtrvtGemmDesc* d) {
   if (gemm_hwgrad_bn(d) != 192) return false;
+  // column stride 2 (conv1 of layer2.0 / 3.0): odd / even pixel images of x, gemm_hwgrad16_kernel<96, 192, 2> -- exact, but MEASURED
+  // SLOWER than the generic gather at its best split (0.422 against 0.410 ms at layer2.0, 0.413 against 0.367 at layer3.0:
+  // 27 + 24 DMA pieces per 288 x 192 k-tile; profiles/r05_experiments.md (j)), so only on request (tile 13: tests, A/B runs)
+  if (d->sw == 2) return d->Cpad % 96 == 0 && d->tile == 13;
   return d->Cpad % 128 != 0 && d->Cpad % 96 == 0 && (d->tile == 0 || d->tile == 13);
 }
 int gemm_hwgrad_cc(const HtrvtGemmDesc* d) { return gemm_hwgrad_is16(d) ? 96 : ((d->Cpad % 128 == 0 || d->tile != 17) ? 128 : 64); }
@@ -25,8 +29,9 @@ int gemm_hwgrad_bn(const HtrvtGemmDesc* d) {
 bool gemm_hwgrad_serves(const HtrvtGemmDesc* d) {
   if (d->gather != HTRVT_GATHER_CONV_WGRAD || d->dtype != HTRVT_BF16) return false;
   if (d->tile != 0 && d->tile != 13 && d->tile != 17 && d->tile != 18) return false;      // 13: this kernel where eligible (17: without unit pairing); 3 / 4 / 6: the generic kernels (A/B)
-  if (d->kh != 3 || d->kw != 3 || (d->sh != 1 && d->sh != 2) || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;   // row stride 2: layer1.0.conv1
-  if (d->Ho != (d->Hi - 1) / d->sh + 1 || d->Wo != d->Wi || (d->Wi % 64) != 0) return false;     // a k-tile = 64 pixels of one image row
+  if (d->kh != 3 || d->kw != 3 || (d->sh != 1 && d->sh != 2) || (d->sw != 1 && d->sw != 2) || d->ph != 1 || d->pw != 1) return false;   // row stride 2: layer1.0.conv1
+  if (d->Ho != (d->Hi - 1) / d->sh + 1 || (d->Wo % 64) != 0) return false;     // a k-tile = 64 pixels of one output row
+  if (d->sw == 1 ? d->Wo != d->Wi : ((d->Wi & 1) || d->Wo != d->Wi / 2 || !gemm_hwgrad_is16(d))) return false;   // column stride 2: conv1 of layer2.0 / 3.0, odd / even pixel images
   if (!d->c_f32 || d->batch > 1 || d->Cpad % 64 != 0 || d->M != 9 * d->Cpad || d->N != d->Co) return false;
   if (d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->colstats != nullptr) return false;
   const long long lim = (1ll << 31) - 64;
@@ -46,7 +51,7 @@ int gemm_hwgrad_try_launch(const HtrvtGemmDesc* d, KParams& p, int zdim, hipStre
   p.tiles_n = (d->N + bn - 1) / bn;
   if (gemm_hwgrad_is16(d)) {
     p.tiles_m = 3 * (d->Cpad / cc);
-    return launch_hwgrad16<96, 192>(p, zdim, st);
+    return d->sw == 2 ? launch_hwgrad16<96, 192, 2>(p, zdim, st) : launch_hwgrad16<96, 192>(p, zdim, st);
   }
   if (gemm_hwgrad_pair(d)) {
     p.tiles_m = (3 * (d->Cpad / 64) + 1) / 2;

@@ -267,20 +267,27 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
 // mid-tile barrier) fit the 168 registers of twelve waves; a 128-channel unit (96 accumulators) would not, so layers 2-3 stay
 // on the kernel above.  The chip also holds a higher clock on this MFMA shape (gemm_halo_impl.h).
 // ---------------------------------------------------------------------------------------------
-template <int CC, int BN>
+// SW = 2 (round 5): the weight gradients of the COLUMN-strided 3x3 convolutions (conv1 of layer2.0 / layer3.0, stride (2,2)).  A k-tile
+// is still 64 output pixels wo0 .. wo0 + 63 of one output row; kernel columns 0 and 2 contract them against the ODD input pixels
+// 2 wo0 - 1 + 2 r (column 2 one row further down) and column 1 against the EVEN pixels 2 wo0 + 2 r: the x stage holds an odd image
+// (LDS rows 0 .. 64) and an even image (rows 80 .. 143: a multiple of 16 rows further down, so the bank pattern of the transposed
+// reads is the one checked for SW = 1) -- 129 pixel rows per k-tile instead of the 3 x 64 of the generic gather, which decoded a
+// pixel per row and tap (layer2.0 / 3.0: 0.41 / 0.37 ms = 850 / 950 TFLOP/s on gemm_dma_kernel<.., 3, ..>).
+template <int CC, int BN, int SW = 1>
 struct Hw16Geo {
   static constexpr int NW = 12, NTH = NW * 64;
   static constexpr int XROWB = CC * 2, XCPR = CC / 8;
-  static constexpr int XPIECES = (66 * XROWB + 1023) / 1024;   // 13 at CC = 96
+  static constexpr int EVEN0 = 80;                             // first LDS row of the even image (SW = 2)
+  static constexpr int XROWS = SW == 1 ? 66 : EVEN0 + 64;
+  static constexpr int XPIECES = (XROWS * XROWB + 1023) / 1024;   // 13 at CC = 96 (SW = 2: 27)
   static constexpr int XBYTES = XPIECES * 1024;
   static constexpr int YROWB = BN * 2, YCPR = BN / 8;
   static constexpr int YBYTES = 64 * YROWB, YPIECES = YBYTES / 1024;
   static constexpr int STAGE = XBYTES + YBYTES, NSTAGE = 3, LDS_BYTES = NSTAGE * STAGE;
   static constexpr int RT = CC / 32, CT = BN / 32;             // 16 x 16 tiles per wave: rows (CC / 2 channels), columns (BN / 2)
   static constexpr int NPX = (XPIECES + NW - 1) / NW, NPY = YPIECES / NW;
-  static_assert(CC == 96 && BN == 192 && YPIECES % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
-  // CC = 96: one k-step's fragments held across the mid-tile barrier (gemm_hwgrad_body); CC = 128 (96 accumulators): no room for
-  // that, the barrier sits between k-tiles
+  static_assert(CC == 96 && BN == 192 && (SW == 1 || SW == 2) && YPIECES % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
+  // one k-step's fragments held across the mid-tile barrier (gemm_hwgrad_body)
   static constexpr bool HOLD = CC == 96;
   static __device__ __forceinline__ int xrot(int r) { return CC == 96 ? 2 * ((r >> 3) & 1) : 4 * (r & 3) + 2 * ((r >> 3) & 1); }
   static __device__ __forceinline__ int yrot(int k) { return BN == 192 ? 4 * ((k >> 1) & 1) + 2 * ((k >> 3) & 1) : 4 * (k & 3) + 2 * ((k >> 3) & 1); }
@@ -288,9 +295,9 @@ struct Hw16Geo {
 
 typedef float f32x4w_t __attribute__((ext_vector_type(4)));
 
-template <int CC, int BN, class P>
+template <int CC, int BN, int SW, class P>
 __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x) {
-  using H = Hw16Geo<CC, BN>;
+  using H = Hw16Geo<CC, BN, SW>;
   constexpr int NW = H::NW, RT = H::RT, CT = H::CT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -324,7 +331,7 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
   const unsigned long long xa = (unsigned long long)p.A, ya = (unsigned long long)p.B;
   const i32x4_t rsrcX = i32x4_t{(int)(unsigned)(xa & 0xffffffffull), (int)(unsigned)((xa >> 32) & 0xffffull), (int)OOB, 0x00020000};
   const i32x4_t rsrcY = i32x4_t{(int)(unsigned)(ya & 0xffffffffull), (int)(unsigned)((ya >> 32) & 0xffffull), (int)OOB, 0x00020000};
-  int xr[H::NPX], xc[H::NPX];
+  int xr[H::NPX], xc[H::NPX];      // xr: source pixel of this lane's LDS row, relative to the k-tile's first (SW = 1: w0 - 1; SW = 2: 2 w0)
   bool xok[H::NPX];
 #pragma unroll
   for (int i = 0; i < H::NPX; ++i) {
@@ -333,9 +340,9 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
     const int r = q / H::XROWB, cd = (q - r * H::XROWB) >> 4;
     int cs = cd - H::xrot(r);
     cs += cs < 0 ? H::XCPR : 0;
-    xr[i] = r;
+    xr[i] = SW == 1 ? r : (r < H::EVEN0 ? 2 * r - 1 : 2 * (r - H::EVEN0));
     xc[i] = cs;
-    xok[i] = pi < H::XPIECES && r < 66 && ciu + cs * 8 < p.Ci;
+    xok[i] = pi < H::XPIECES && (SW == 1 ? r < 66 : (r < 65 || (r >= H::EVEN0 && r < H::EVEN0 + 64))) && ciu + cs * 8 < p.Ci;
   }
   unsigned yoff[H::NPY];
   int ykr[H::NPY];
@@ -350,18 +357,19 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
     yoff[i] = col < p.N ? (unsigned)kr * (unsigned)(p.ldb * 2) + (unsigned)col * 2u : OOB;
   }
   const unsigned lds0 = lds_addr_of(smem);
-  const int Hh = p.Hi, Ww = p.Wi;
-  int iq_row = kbeg / Ww, iq_w0 = kbeg - iq_row * Ww, iq_k = kbeg;
+  const int Hh = p.Hi, Ww = p.Wi, Wk = p.Wo;        // a k-tile = 64 pixels of one OUTPUT row (Wo = Wi at SW = 1)
+  int iq_row = kbeg / Wk, iq_w0 = kbeg - iq_row * Wk, iq_k = kbeg;
   auto issue = [&](int stage) {
     const unsigned sbase = lds0 + stage * H::STAGE;
     const int bimg = iq_row / p.Ho, hrow = iq_row - bimg * p.Ho;
     const int hh = hrow * p.sh + dyu - 1;
     const bool rowok = iq_k < kend && (unsigned)hh < (unsigned)Hh;
-    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + iq_w0 - 1) * p.Ci + ciu) * 2u;   // pixel w0 - 1 of the source row (may wrap: masked)
+    const int wfirst = SW == 1 ? iq_w0 - 1 : 2 * iq_w0;
+    const unsigned gbase = (unsigned)(((bimg * Hh + hh) * Ww + wfirst) * p.Ci + ciu) * 2u;   // pixel wfirst of the source row (may wrap: masked)
 #pragma unroll
     for (int i = 0; i < H::NPX; ++i) {
       if (wave + NW * i < H::XPIECES) {      // wave-uniform
-        const int w = iq_w0 - 1 + xr[i];
+        const int w = wfirst + xr[i];
         const bool v = rowok && xok[i] && (unsigned)w < (unsigned)Ww;
         const unsigned voff = v ? gbase + (unsigned)(xr[i] * p.Ci + xc[i] * 8) * 2u : OOB;
         dma16(rsrcX, __builtin_amdgcn_readfirstlane(sbase + (wave + NW * i) * 1024), voff);
@@ -375,7 +383,7 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
     }
     iq_k += BK;
     iq_w0 += BK;
-    if (iq_w0 >= Ww) {
+    if (iq_w0 >= Wk) {
       iq_w0 = 0;
       ++iq_row;
     }
@@ -400,7 +408,8 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   typedef __attribute__((address_space(3))) s16x4_t* lptr;
   auto xfrag = [&](const char* xs, int i, int s) {
-    const int r0 = 32 * s + 8 * g + q + dx;
+    // SW = 2: kernel column 0 / 2 = odd image at row shift 0 / 1, column 1 = even image
+    const int r0 = 32 * s + 8 * g + q + (SW == 1 ? dx : (dx == 1 ? H::EVEN0 : (dx >> 1)));
     const int cb = (crow + 16 * i) / 8 + (pp >> 1);
     int c0 = cb + H::xrot(r0), c1 = cb + H::xrot(r0 + 4);
     c0 -= c0 >= H::XCPR ? H::XCPR : 0;
@@ -504,19 +513,19 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
     }
 }
 
-template <int CC, int BN>
+template <int CC, int BN, int SW = 1>
 __global__ __launch_bounds__(768) void gemm_hwgrad16_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;
   (void)p;
   KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
-  gemm_hwgrad16_body<CC, BN>(*kp, (int)blockIdx.x);
+  gemm_hwgrad16_body<CC, BN, SW>(*kp, (int)blockIdx.x);
 }
 
-template <int CC, int BN>
+template <int CC, int BN, int SW = 1>
 int launch_hwgrad16(const KParams& p, int zdim, hipStream_t st) {
-  using H = Hw16Geo<CC, BN>;
+  using H = Hw16Geo<CC, BN, SW>;
   static bool attr_done = false;
-  auto kern = gemm_hwgrad16_kernel<CC, BN>;
+  auto kern = gemm_hwgrad16_kernel<CC, BN, SW>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
     if (e != hipSuccess) {
@@ -529,7 +538,8 @@ int launch_hwgrad16(const KParams& p, int zdim, hipStream_t st) {
   dim3 grid(ntiles, 1, zdim);
   if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
-  set_last_kernel("gemm_hwgrad16_kernel<%d, %d>", CC, BN);
+  if (SW == 1) set_last_kernel("gemm_hwgrad16_kernel<%d, %d>", CC, BN);
+  else set_last_kernel("gemm_hwgrad16_kernel<%d, %d, %d>", CC, BN, SW);
   const int rc = check_launch("gemm_hwgrad16_kernel");
   return rc ? rc : 1;
 }

@@ -253,6 +253,36 @@ def test_halo_conv_col_stride_forward_exact(cfg):
     assert torch.equal(yd.double().cpu(), ref.to(BF).double()), _last_kernel()
 
 
+@pytest.mark.parametrize("cfg", [(2, 8, 256, 192, 384, (2, 2)),     # layer2.0-like: two 96-channel chunks, two 192-column tiles
+                                 (3, 5, 128, 384, 192, (2, 2)),     # odd H, four chunks, one k-tile per output row
+                                 (1, 3, 512, 192, 320, (1, 2)),     # row stride 1; Co = 320: a ragged second column tile
+                                 (2, 4, 128, 96, 192, (2, 2))])     # Cpad 128 is not a multiple of 96: the generic kernel must serve it
+def test_halo_conv_col_stride_wgrad_exact(cfg):
+    """weight gradient of the column-strided 3x3 convolutions (gemm_hwgrad16_kernel<96, 192, 2>: odd / even pixel images of x) against
+    torch's float64 autograd on integer data: slabs and atomics, XCD-grouped and ragged split factors, the generic gather beside it"""
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co, stride = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=95)
+    w = T._ints((Co, Ci, 3, 3), -2, 3, seed=96).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=stride, padding=1)
+    dy = T._ints(tuple(y.shape), -2, 3, seed=97)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, stride, 1)
+    M = Bn * geom.Ho * geom.Wo
+    cpi = ops.cpad(Ci, BF)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    want = T._pack_fwd(w.grad, cpi).permute(1, 2, 0)            # [taps][Cpad][Co]
+    for tile, split_k in ((13, 8), (13, 3), (13, 1), (3, 8)):
+        base = T._ints((9, cpi, Co), -5, 6, seed=98)
+        dwp = base.float().cuda()
+        ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                 gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, tile=tile)
+        if tile == 13 and cpi % 96 == 0:
+            assert "gemm_hwgrad16_kernel<96, 192, 2>" in _last_kernel(), _last_kernel()
+        assert torch.equal(dwp.double().cpu(), base + want), (tile, split_k, _last_kernel(), float((dwp.double().cpu() - base - want).abs().max()))
+
+
 @pytest.mark.parametrize("cfg", HALO)
 def test_halo_conv_forward_dgrad_exact(cfg):
     ops = T._ops()

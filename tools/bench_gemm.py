@@ -127,6 +127,7 @@ def main():
         split_h = eng_._split_k(g.taps * Ci, Co, M, conv=True, tiling=eng_._hwgrad_tiles(g))    # halo-staged kernel's tiling
         split = eng_._split_k(g.taps * Ci, Co, M, conv=True)                                     # generic kernel
         split = int(os.environ.get('HTRVT_BENCH_SPLITK', split))
+        split_h = int(os.environ.get('HTRVT_BENCH_SPLITH', split_h))
         split17 = eng_._split_k(g.taps * Ci, Co, M, conv=True, tiling=(3 * (Ci // 64) * ((Co + 191) // 192), 192, 192))   # tile 17: unpaired 64-channel tiles
         ms = timeit(lambda: ops.gemm(x, y, dw, dtype=dt, M=g.taps * Ci, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR,
                                      b_layout=ops.MNMAJOR, gather=ops.GATHER_CONV_WGRAD, geom=g, Cpad=Ci,

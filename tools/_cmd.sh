@@ -1,4 +1,3 @@
-O=gpurun_out/r05h; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gemm8p_gpu.py -m gpu -x -q -k "halo or fused" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log
-timeout -k 10 400 python tools/bench_gemm.py --only s1conv --tiles 21 20 --rounds 3 > $O/persist_ab.log 2>&1; echo "ab rc=$?"; cat $O/persist_ab.log
-timeout -k 10 400 python tools/bench_gemm.py --only fdgrad --tiles 21 20 --rounds 2 > $O/persist_fd.log 2>&1; echo "fd rc=$?"; cat $O/persist_fd.log
+O=gpurun_out/r05i; mkdir -p $O
+timeout -k 10 300 python -m pytest tests/test_model_gpu.py -m gpu -x -q -s -k "forward_decisions or tiny_model_logits" > $O/tiny.log 2>&1; echo "tiny rc=$?"; grep -E "tiny|passed|failed|Error" $O/tiny.log | cut -c1-900
+timeout -k 10 900 python -m pytest tests/test_full_shape_gpu.py -m gpu -x -q -s -k "across_paths" > $O/full.log 2>&1; echo "full rc=$?"; grep -E "split-bf16 vs float32|passed|failed|Error|assert" $O/full.log | cut -c1-1200

@@ -320,7 +320,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
 // pass B: dx = cA*g + cB*x + cC ; optionally also writes g (the ReLU-masked incoming gradient)
 // The 3 C coefficients sit in LDS (per element loads from global were 24 of the 27 loads of a vector) and the channel
 // index of a thread's vector advances by a constant per grid stride (no 64-bit modulo per vector).
-template <typename T>
+// STREAM: the inputs by non-temporal loads (ld_stream16) -- activations of >= bn_stream_bytes() that no cache will hold until their
+// next reader; smaller ones (layer 3: 50 MB) are served from the memory-side cache and lose with them (A/B in profiles/r05_experiments.md (m))
+template <typename T, bool STREAM>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ yact,
                                                           const T* __restrict__ x, const float* __restrict__ coef,
                                                           T* __restrict__ dx, T* __restrict__ gout, long long nvec,
@@ -337,9 +339,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   for (; i < nvec; i += stride) {
     const float* ca = sco + cv * CH;
     Vec16<T> vd, vx, vy, o, go;
-    vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dy)[i];
-    vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
-    if (yact) vy.raw = reinterpret_cast<const decltype(vy.raw)*>(yact)[i];
+    if constexpr (STREAM) {
+      vd.raw = ld_stream16(reinterpret_cast<const decltype(vd.raw)*>(dy) + i);
+      vx.raw = ld_stream16(reinterpret_cast<const decltype(vx.raw)*>(x) + i);
+      if (yact) vy.raw = ld_stream16(reinterpret_cast<const decltype(vy.raw)*>(yact) + i);
+    } else {
+      vd.raw = reinterpret_cast<const decltype(vd.raw)*>(dy)[i];
+      vx.raw = reinterpret_cast<const decltype(vx.raw)*>(x)[i];
+      if (yact) vy.raw = reinterpret_cast<const decltype(vy.raw)*>(yact)[i];
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float g = vd.get(j);
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
 // pass B for the two BatchNorms that consume the SAME gradient (a stage's first block: bn2 of the main branch and the
 // downsample BN both receive the masked gradient of the block output, resnet18.py:33-37): g is read once,
 // dx1 = c1A*g + c1B*x1 + c1C and dx2 = c2A*g + c2B*x2 + c2C.  5 streams instead of 6.
-template <typename T>
+template <typename T, bool STREAM>
 __global__ __launch_bounds__(NT) void bn_bwd_apply2_kernel(const T* __restrict__ g, const T* __restrict__ x1, const float* __restrict__ coef1,
                                                            T* __restrict__ dx1, const T* __restrict__ x2, const float* __restrict__ coef2,
                                                            T* __restrict__ dx2, long long nvec, int C) {
@@ -377,9 +385,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_kernel(const T* __restrict__
     const float* ca = sco + cv * CH;
     const float* cb = ca + 3 * C;
     Vec16<T> vg, v1, v2, o1, o2;
-    vg.raw = reinterpret_cast<const decltype(vg.raw)*>(g)[i];
-    v1.raw = reinterpret_cast<const decltype(v1.raw)*>(x1)[i];
-    v2.raw = reinterpret_cast<const decltype(v2.raw)*>(x2)[i];
+    if constexpr (STREAM) {
+      vg.raw = ld_stream16(reinterpret_cast<const decltype(vg.raw)*>(g) + i);
+      v1.raw = ld_stream16(reinterpret_cast<const decltype(v1.raw)*>(x1) + i);
+      v2.raw = ld_stream16(reinterpret_cast<const decltype(v2.raw)*>(x2) + i);
+    } else {
+      vg.raw = reinterpret_cast<const decltype(vg.raw)*>(g)[i];
+      v1.raw = reinterpret_cast<const decltype(v1.raw)*>(x1)[i];
+      v2.raw = reinterpret_cast<const decltype(v2.raw)*>(x2)[i];
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const float gg = vg.get(j);
@@ -889,8 +903,13 @@ extern "C" int htrvt_bn_bwd_apply(const void* dy, const void* yact, const void* 
   HTRVT_REQUIRE(C % ch == 0, "htrvt_bn_bwd_apply: C=%d unsupported", C);
   const long long nvec = npix * (C / ch);
   dim3 grid(grid_for(nvec));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(NT), (size_t)3 * C * sizeof(float), (hipStream_t)stream, (const T*)dy,
-                                       (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
+  if (nvec * 16 >= bn_stream_bytes()) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), grid, dim3(NT), (size_t)3 * C * sizeof(float), (hipStream_t)stream, (const T*)dy,
+                                         (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), grid, dim3(NT), (size_t)3 * C * sizeof(float), (hipStream_t)stream, (const T*)dy,
+                                         (const T*)yact, (const T*)x, coef, (T*)dx, (T*)gout, nvec, C));
+  }
   return check_launch("bn_bwd_apply");
 }
 
@@ -901,8 +920,13 @@ extern "C" int htrvt_bn_bwd_apply2(const void* g, const void* x1, const float* c
   HTRVT_REQUIRE(g && x1 && x2 && coef1 && coef2 && dx1 && dx2, "htrvt_bn_bwd_apply2: null buffer");
   const long long nvec = npix * (C / ch);
   dim3 grid(grid_for(nvec));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply2_kernel<T>, grid, dim3(NT), (size_t)6 * C * sizeof(float), (hipStream_t)stream, (const T*)g,
-                                       (const T*)x1, coef1, (T*)dx1, (const T*)x2, coef2, (T*)dx2, nvec, C));
+  if (nvec * 16 >= bn_stream_bytes()) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, true>), grid, dim3(NT), (size_t)6 * C * sizeof(float), (hipStream_t)stream, (const T*)g,
+                                         (const T*)x1, coef1, (T*)dx1, (const T*)x2, coef2, (T*)dx2, nvec, C));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, false>), grid, dim3(NT), (size_t)6 * C * sizeof(float), (hipStream_t)stream, (const T*)g,
+                                         (const T*)x1, coef1, (T*)dx1, (const T*)x2, coef2, (T*)dx2, nvec, C));
+  }
   return check_launch("bn_bwd_apply2");
 }
 

@@ -1,5 +1,6 @@
 // common.h -- shared device/host helpers for the gfx950 kernels.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -81,6 +82,30 @@ struct Vec16<bf16_t> {
 #endif
   }
 };
+
+// 16-byte streaming (non-temporal) load / store: tensors that are read or written ONCE per pass and are far larger than the L2
+// (the BatchNorm apply / backward-apply passes over 100 ... 400 MB activations; htrvt_adamw's moments: 276 -> 240 us with them)
+template <class RAW>
+__device__ __forceinline__ RAW ld_stream16(const RAW* p) {
+  typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(RAW) == 16, "16-byte vectors");
+  return __builtin_bit_cast(RAW, __builtin_nontemporal_load(reinterpret_cast<const u32x4s_t*>(p)));
+}
+template <class RAW>
+__device__ __forceinline__ void st_stream16(RAW* p, const RAW& v) {
+  typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(RAW) == 16, "16-byte vectors");
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4s_t, v), reinterpret_cast<u32x4s_t*>(p));
+}
+
+// tensors of at least this many bytes are streamed by the BatchNorm passes (HTRVT_BN_STREAM_MB overrides: A/B runs; 0 = always, a huge value = never)
+inline long long bn_stream_bytes() {
+  static const long long v = [] {
+    const char* e = getenv("HTRVT_BN_STREAM_MB");
+    return (e != nullptr ? atoll(e) : 150ll) << 20;
+  }();
+  return v;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

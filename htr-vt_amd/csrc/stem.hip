@@ -562,7 +562,8 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // stride (per element loads from global and a 64-bit modulo per vector were most of the kernel's instructions).
 // MASK (bfloat16, 8 elements per vector): byte i of `mask` = the signs of vector i's outputs, bit j set where y[8 i + j] > 0
 // -- the ReLU's backward reads this bit instead of y (HtrvtGemmDesc.relu_bits).
-template <typename T, int RES, bool MASK = false>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
+// STREAM: inputs by non-temporal loads, for activations of >= bn_stream_bytes() (common.h)
+template <typename T, int RES, bool MASK = false, bool STREAM = false>  // RES: 0 none, 1 identity residual, 2 residual with its own BN coefficients
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -587,8 +588,13 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
   for (; i < nvec; i += stride) {
     const float* ca = sco + cv * CH;
     Vec16<T> v, r, o;
-    v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[i];
-    if constexpr (RES != 0) r.raw = reinterpret_cast<const decltype(r.raw)*>(res)[i];
+    if constexpr (STREAM) {
+      v.raw = ld_stream16(reinterpret_cast<const decltype(v.raw)*>(x) + i);
+      if constexpr (RES != 0) r.raw = ld_stream16(reinterpret_cast<const decltype(r.raw)*>(res) + i);
+    } else {
+      v.raw = reinterpret_cast<const decltype(v.raw)*>(x)[i];
+      if constexpr (RES != 0) r.raw = reinterpret_cast<const decltype(r.raw)*>(res)[i];
+    }
     unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -864,8 +870,14 @@ extern "C" int htrvt_bn_apply(const void* x, const float* scale, const float* sh
   dim3 grid(grid_for(nvec));
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BN_APPLY(T, R)                                                                                            \
-  hipLaunchKernelGGL((bn_apply_kernel<T, R>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st, (const T*)x, scale, shift, (const T*)res, rscale, \
-                     rshift, (T*)y, nvec, C, relu)
+  do {                                                                                                                   \
+  if (nvec * 16 >= bn_stream_bytes())                                                                                    \
+    hipLaunchKernelGGL((bn_apply_kernel<T, R, false, true>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st, (const T*)x, scale, shift, (const T*)res, rscale, \
+                       rshift, (T*)y, nvec, C, relu);                                                                    \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((bn_apply_kernel<T, R>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st, (const T*)x, scale, shift, (const T*)res, rscale, \
+                       rshift, (T*)y, nvec, C, relu);                                                                    \
+  } while (0)
   if (dtype == HTRVT_BF16) {
     if (mode == 0) LAUNCH_BN_APPLY(bf16_t, 0);
     else if (mode == 1) LAUNCH_BN_APPLY(bf16_t, 1);
@@ -889,8 +901,14 @@ extern "C" int htrvt_bn_apply_mask(const void* x, const float* scale, const floa
   dim3 grid(grid_for(nvec));
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BN_APPLY_MASK(R)                                                                                              \
-  hipLaunchKernelGGL((bn_apply_kernel<bf16_t, R, true>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st,   \
-                     (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, (bf16_t*)y, nvec, C, relu, mask)
+  do {                                                                                                                       \
+  if (nvec * 16 >= bn_stream_bytes())                                                                                        \
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t, R, true, true>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st, \
+                       (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, (bf16_t*)y, nvec, C, relu, mask);  \
+  else                                                                                                                       \
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t, R, true>), grid, dim3(NT), (size_t)(R == 2 ? 4 : 2) * C * sizeof(float), st,  \
+                       (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, (bf16_t*)y, nvec, C, relu, mask); \
+  } while (0)
   if (mode == 0) LAUNCH_BN_APPLY_MASK(0);
   else if (mode == 1) LAUNCH_BN_APPLY_MASK(1);
   else LAUNCH_BN_APPLY_MASK(2);

@@ -1,3 +1,10 @@
-O=gpurun_out/r05i; mkdir -p $O
-timeout -k 10 300 python -m pytest tests/test_model_gpu.py -m gpu -x -q -s -k "forward_decisions or tiny_model_logits" > $O/tiny.log 2>&1; echo "tiny rc=$?"; grep -E "tiny|passed|failed|Error" $O/tiny.log | cut -c1-900
-timeout -k 10 900 python -m pytest tests/test_full_shape_gpu.py -m gpu -x -q -s -k "across_paths" > $O/full.log 2>&1; echo "full rc=$?"; grep -E "split-bf16 vs float32|passed|failed|Error|assert" $O/full.log | cut -c1-1200
+O=gpurun_out/r05k; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+for rep in 1 2; do for v in 100000 300 150 0; do
+HTRVT_BN_STREAM_MB=$v timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-path > $O/ab_${v}_$rep.json 2>$O/ab.err; python -c "import json;d=json.load(open('$O/ab_${v}_$rep.json'));print('stream_mb=$v b128',d['ms_per_step'])"
+done; done
+cd /tmp && export TMPDIR=/tmp
+for v in 100000 150; do
+export HTRVT_BN_STREAM_MB=$v
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$v -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-path --no-overlap-wgrad > $R/$O/prof_$v.log 2>&1; echo "prof $v rc=$?"
+done

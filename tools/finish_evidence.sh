@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev container, after `gpurun -- bash tools/round_evidence.sh <tag>`: turn gpurun_out/<tag>/ into the committed summaries.
 #   tools/finish_evidence.sh <tag> [round]      e.g. tools/finish_evidence.sh r04a r04
-TAG=${1:?tag}; RND=${2:-r04}
+TAG=${1:?tag}; RND=${2:-r05}
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
 python tools/make_round_docs.py gpurun_out/$TAG $RND || exit 1
 python tools/prof_summary.py gpurun_out/$TAG/prof profiles/${RND}_step_bf16_b128.md --steps 9 \

@@ -62,7 +62,7 @@ def main():
     # ---- parity log
     plog = os.path.join(src, "parity.log")
     if os.path.exists(plog):
-        keep = [l.rstrip() for l in open(plog) if any(k in l for k in ("max-abs", "cosine", "agreement", "passed", "failed", "loss"))]
+        keep = [l.rstrip() for l in open(plog) if any(k in l for k in ("max-abs", "cosine", "agreement", "passed", "failed", "loss", "decisions", "rel-L2"))]
         with open(os.path.join(prof, f"{tag}_parity.md"), "w") as f:
             f.write(f"# Round {tag[1:]}: parity numbers printed by the GPU tests\n\n"
                     "`python -m pytest tests/test_full_shape_gpu.py tests/test_model_gpu.py tests/test_train_iter_gpu.py -m gpu -s -q` on one MI355X "

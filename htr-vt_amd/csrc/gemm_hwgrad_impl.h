@@ -23,6 +23,23 @@
 
 namespace {
 
+// Split factors that are not multiples of 8 (layer 2: 14 ranges x 18 tiles, layer 3: 7 x 72, layer 1: 42 x 6): workgroup b runs on
+// XCD b % 8, so the workgroups of XCD x are b = x, x + 8, ...; give them CONSECUTIVE (range, tile) pairs -- XCD x holds the linear
+// indices [P_x, P_x + n_x) -- and every pixel range lies on one XCD or straddles two, instead of being dealt over all eight (each
+// range's x / dY rows were then fetched into eight L2s: 4.8x the operand bytes at layer 2, profiles/r05_pmc.md).
+__device__ __forceinline__ void xcd_range_map(int b, int total, int ntiles, int& z, int& id) {
+  const int x = b & 7, s = b >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int L = x * q + (x < r ? x : r) + s;
+  z = L / ntiles;
+  id = L - z * ntiles;
+}
+
+inline bool hwgrad_xcd_ranges() {      // HTRVT_NO_XCD_RANGES=1: the z-grid of rounds 3-4 for split factors that are not multiples of 8 (A/B runs)
+  static const bool off = getenv("HTRVT_NO_XCD_RANGES") != nullptr && getenv("HTRVT_NO_XCD_RANGES")[0] == '1';
+  return !off;
+}
+
 template <int CC, int BN>
 struct HwGeo {
   static constexpr int NW = 12, NTH = NW * 64;
@@ -70,6 +87,8 @@ __device__ __forceinline__ void gemm_hwgrad_body(const P& p, const int block_x) 
     const int chunk = block_x / (8 * ntiles), r = block_x - chunk * 8 * ntiles;
     z = chunk * 8 + (r & 7);
     id = r >> 3;
+  } else if (p.split_k > 1 && gridDim.z == 1) {
+    xcd_range_map(block_x, (int)gridDim.x, ntiles, z, id);
   }
   const int tm = id / p.tiles_n, tile_n = id - tm * p.tiles_n;
   // unit u of this workgroup (PAIR: two, else one): kernel row dyu[u], first channel ciu[u]; a missing second unit reads zeros
@@ -309,6 +328,8 @@ __device__ __forceinline__ void gemm_hwgrad16_body(const P& p, const int block_x
     const int chunk = block_x / (8 * ntiles), r = block_x - chunk * 8 * ntiles;
     z = chunk * 8 + (r & 7);
     id = r >> 3;
+  } else if (p.split_k > 1 && gridDim.z == 1) {
+    xcd_range_map(block_x, (int)gridDim.x, ntiles, z, id);
   }
   const int tm = id / p.tiles_n, tile_n = id - tm * p.tiles_n;
   const int dyu = tm / NCC, ciu = (tm - dyu * NCC) * CC;
@@ -536,7 +557,7 @@ int launch_hwgrad16(const KParams& p, int zdim, hipStream_t st) {
   }
   const int ntiles = 3 * (p.Cpad / CC) * p.tiles_n;
   dim3 grid(ntiles, 1, zdim);
-  if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
+  if (p.split_k > 1 && ((p.split_k & 7) == 0 || hwgrad_xcd_ranges())) grid = dim3(p.split_k * ntiles, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
   if (SW == 1) set_last_kernel("gemm_hwgrad16_kernel<%d, %d>", CC, BN);
   else set_last_kernel("gemm_hwgrad16_kernel<%d, %d, %d>", CC, BN, SW);
@@ -567,7 +588,7 @@ int launch_hwgrad(const KParams& p, int zdim, hipStream_t st) {
   }
   const int ntiles = (PAIR ? (3 * (p.Cpad / 64) + 1) / 2 : 3 * (p.Cpad / CC)) * p.tiles_n;
   dim3 grid(ntiles, 1, zdim);
-  if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * ntiles, 1, 1);
+  if (p.split_k > 1 && ((p.split_k & 7) == 0 || hwgrad_xcd_ranges())) grid = dim3(p.split_k * ntiles, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(768), H::LDS_BYTES, st, p);
   set_last_kernel(PAIR ? "gemm_hwgrad_kernel<%d, %d, true>" : "gemm_hwgrad_kernel<%d, %d>", CC, BN);
   const int rc = check_launch("gemm_hwgrad_kernel");

@@ -60,6 +60,23 @@ __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
 
+// Split factors that are not multiples of 8 (layer 2: 14 ranges x 18 tiles, layer 3: 7 x 72, layer 1: 42 x 6): workgroup b runs on
+// XCD b % 8, so the workgroups of XCD x are b = x, x + 8, ...; give them CONSECUTIVE (range, tile) pairs -- XCD x holds the linear
+// indices [P_x, P_x + n_x) -- and every pixel range lies on one XCD or straddles two, instead of being dealt over all eight (each
+// range's x / dY rows were then fetched into eight L2s: 4.8x the operand bytes at layer 2, profiles/r05_pmc.md).
+__device__ __forceinline__ void xcd_range_map(int b, int total, int ntiles, int& z, int& id) {
+  const int x = b & 7, s = b >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int L = x * q + (x < r ? x : r) + s;
+  z = L / ntiles;
+  id = L - z * ntiles;
+}
+
+inline bool hwgrad_xcd_ranges() {      // HTRVT_NO_XCD_RANGES=1: the z-grid of rounds 3-4 for split factors that are not multiples of 8 (A/B runs)
+  static const bool off = getenv("HTRVT_NO_XCD_RANGES") != nullptr && getenv("HTRVT_NO_XCD_RANGES")[0] == '1';
+  return !off;
+}
+
 template <int ROWS, int NWAVES = 8, int KB = 64>   // KB = k-tile depth in elements (64, or 32 for the deep pipeline)
 struct Geo {
   static constexpr int BYTES = ROWS * KB * 2;           // both layouts
@@ -794,6 +811,8 @@ __device__ __forceinline__ void gemm_dma_body(const P& p, const int block_x) {
     const int chunk = L / (8 * ntiles), r = L - chunk * 8 * ntiles;
     z = chunk * 8 + (r & 7);
     id = r >> 3;
+  } else if (p.split_k > 1 && gridDim.z == 1) {     // any other split factor: consecutive (range, tile) pairs per XCD
+    xcd_range_map(block_x, (int)gridDim.x, ntiles, z, id);
   } else if (p.split_k == 1 && (ntiles & 7) == 0) {
     id = (id & 7) * (ntiles >> 3) + (id >> 3);
   }
@@ -1074,7 +1093,7 @@ int launch(const KParams& p, int zdim, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, zdim);
-  if (p.split_k > 1 && (p.split_k & 7) == 0) grid = dim3(p.split_k * p.tiles_m * p.tiles_n, 1, 1);   // XCD-grouped K ranges
+  if (p.split_k > 1 && ((p.split_k & 7) == 0 || hwgrad_xcd_ranges())) grid = dim3(p.split_k * p.tiles_m * p.tiles_n, 1, 1);   // XCD-grouped K ranges
   hipLaunchKernelGGL(kern, grid, dim3(NTH), smem, st, p);
   set_last_kernel("gemm_dma_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, AL, BL, GATHER, SPEC, NSTAGE);
   const int rc = check_launch("gemm_dma_kernel");

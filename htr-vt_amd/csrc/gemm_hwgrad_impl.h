@@ -23,23 +23,6 @@
 
 namespace {
 
-// Split factors that are not multiples of 8 (layer 2: 14 ranges x 18 tiles, layer 3: 7 x 72, layer 1: 42 x 6): workgroup b runs on
-// XCD b % 8, so the workgroups of XCD x are b = x, x + 8, ...; give them CONSECUTIVE (range, tile) pairs -- XCD x holds the linear
-// indices [P_x, P_x + n_x) -- and every pixel range lies on one XCD or straddles two, instead of being dealt over all eight (each
-// range's x / dY rows were then fetched into eight L2s: 4.8x the operand bytes at layer 2, profiles/r05_pmc.md).
-__device__ __forceinline__ void xcd_range_map(int b, int total, int ntiles, int& z, int& id) {
-  const int x = b & 7, s = b >> 3;
-  const int q = total >> 3, r = total & 7;
-  const int L = x * q + (x < r ? x : r) + s;
-  z = L / ntiles;
-  id = L - z * ntiles;
-}
-
-inline bool hwgrad_xcd_ranges() {      // HTRVT_NO_XCD_RANGES=1: the z-grid of rounds 3-4 for split factors that are not multiples of 8 (A/B runs)
-  static const bool off = getenv("HTRVT_NO_XCD_RANGES") != nullptr && getenv("HTRVT_NO_XCD_RANGES")[0] == '1';
-  return !off;
-}
-
 template <int CC, int BN>
 struct HwGeo {
   static constexpr int NW = 12, NTH = NW * 64;

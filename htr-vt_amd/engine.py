@@ -412,7 +412,14 @@ class Engine:
         # multiples of 8 let the kernel keep all tiles of one K range on one XCD (shared L2); small factors otherwise
         # a single output tile (the 1x1 downsample weight gradients, K = 1 M pixels at layer 1): up to one K range per CU
         smax = 257 if tiles == 1 else 129
-        for s in [1, 2, 3, 4, 5, 6, 7] + list(range(8, smax, 8)) + ([10, 12, 14, 20, 28] if tiling is not None else []):
+        # round 5: the split-K kernels keep the (range, tile) pairs of one XCD consecutive for ANY split factor (xcd_range_map,
+        # csrc/gemm_dma_impl.h), so every factor up to 64 is a candidate for the conv / MN-major launches, not only the multiples
+        # of 8 and a hand-picked few; HTRVT_SPLITK_LEGACY=1 restores the former candidate list and its 10 % penalty (A/B runs)
+        legacy = os.environ.get("HTRVT_SPLITK_LEGACY", "0") == "1" or os.environ.get("HTRVT_NO_XCD_RANGES", "0") == "1"
+        cands = [1, 2, 3, 4, 5, 6, 7] + list(range(8, smax, 8)) + ([10, 12, 14, 20, 28] if tiling is not None else [])
+        if not legacy and (conv or tiling is not None):
+            cands = sorted(set(cands) | set(range(8, 65)))
+        for s in cands:
             if Kred // s < 512:
                 continue
             blocks = tiles * s
@@ -420,7 +427,7 @@ class Engine:
             # every block's float32 output tile: atomics ~1.3 TB/s chip-wide; slabs are written and read back once at HBM speed
             t = flops / 1.0e15 * (rounds * 256.0 / blocks) + blocks * bm * bn * 4 / (2.5e12 if self.deterministic and s > 1 else 1.3e12)
             if s > 1 and s % 8:
-                t *= 1.10     # no XCD grouping of the K ranges: 4-7x the operand traffic (profiles/r01_gemm_hbm_traffic_pmc.md)
+                t *= 1.10 if legacy else 1.02     # (legacy: no XCD grouping of the K ranges, 4-7x the operand traffic; now: a range may straddle two XCDs)
             if best_t is None or t < best_t:
                 best, best_t = s, t
         return best

@@ -442,6 +442,35 @@ def test_halo_conv_wgrad_exact(cfg, slabs):
         assert torch.equal(dwp.double().cpu(), base + want), (tile, float((dwp.double().cpu() - base - want).abs().max()))
 
 
+@pytest.mark.parametrize("split_k", [2, 5, 7, 9, 13, 21, 42])
+def test_wgrad_any_split_factor_exact(split_k):
+    """round 5: split factors that are not multiples of 8 run on a 1-D grid with (range, tile) pairs consecutive per XCD
+    (xcd_range_map, csrc/gemm_dma_impl.h) -- a bijection of workgroup ids for every (tiles, split) pair, also where the workgroup
+    count is not a multiple of 8.  Conv weight gradient on integer data through the three split-K kernels (halo 32x32x16, halo
+    16x16x32 with 96-channel units, generic MN-major gather), slabs and atomics, ranges that do not divide the pixel count."""
+    ops = T._ops()
+    for Bn, Hh, Ww, Ci, Co in ((3, 3, 192, 384, 192), (2, 5, 128, 192, 384)):      # 9 x 1 / 6 x 2 halo tiles; 1 728 / 1 280 pixels
+        x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=74)
+        w = T._ints((Co, Ci, 3, 3), -1, 2, seed=75).requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=1, padding=1)
+        dy = T._ints(tuple(y.shape), -2, 3, seed=76)
+        y.backward(dy)
+        geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (1, 1), 1)
+        M = Bn * Hh * Ww
+        cpi = ops.cpad(Ci, BF)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+        dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+        want = T._pack_fwd(w.grad, cpi).permute(1, 2, 0)
+        for tile in (13, 3):
+            for slabs in (False, True):
+                base = T._ints((9, cpi, Co), -5, 6, seed=77)
+                dwp = base.float().cuda()
+                ws = torch.empty(split_k, 9 * cpi, Co, dtype=torch.float32, device="cuda") if slabs else None
+                ops.gemm(xd, dyd, dwp, dtype=BF, M=9 * cpi, N=Co, K=M, lda=Ci, ldb=Co, ldc=Co, a_layout=ops.MNMAJOR, b_layout=ops.MNMAJOR,
+                         gather=ops.GATHER_CONV_WGRAD, geom=geom, Cpad=cpi, split_k=split_k, accumulate=True, c_f32=True, splitk_ws=ws, tile=tile)
+                assert torch.equal(dwp.double().cpu(), base + want), (split_k, tile, slabs, _last_kernel(), float((dwp.double().cpu() - base - want).abs().max()))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Persistent form (csrc/gemm8pp_impl.h): one workgroup per CU walks its tiles, the epilogue of a tile is folded into the
 # first k-tile of the next.  Shapes with MORE tiles than CUs (several tiles per workgroup: the folded flush), exactly as

@@ -73,3 +73,9 @@ int gemm_halo_s2_try_launch(const HtrvtGemmDesc* d, KParams& p, hipStream_t st, 
 }
 
 }  // namespace htrvt
+
+#ifdef HTRVT_EXP_STAMP
+extern "C" int htrvt_debug_read_halo(void* dst, int nbytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(htrvt_dbg), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -691,12 +691,15 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
 
   if (wave < NWC) {
     // ================================ consumer waves: fragments + MFMA, nothing else ================================
+    HTRVT_STAMP(0);
     f32x4h_t a4[2 * TM][2 * TN];
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * TN; ++j) a4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_barrier();
+    HTRVT_STAMP(1);
+    HTRVT_STAMP(2);
     for (int g = 0; g < NG; ++g) {
       const char* sa = smem + (g & 1) * H::A_STAGE;
       halo_mma16<BN, TM, TN>(a4, sa, smem + H::B_BASE + 0 * H::B_STAGE, DGRAD ? 2 : 0, wm, wn, lane);
@@ -707,9 +710,20 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_s_barrier();
+    HTRVT_STAMP(3);
     f32x16_t acc[TM][TN];
     halo_acc16_to_32<TM, TN>(acc, a4);
     epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+    HTRVT_STAMP(6);
+#ifdef HTRVT_EXP_STAMP      // experiment builds: when have this wave's stores drained, and on which CU did the tile run
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HTRVT_STAMP(7);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      htrvt_dbg[blockIdx.x * 16 + 8] = hw;
+    }
+#endif
   } else {
     // ================================ loader waves: LDS-DMA of the operands, then the side tile ================================
     const int lw = (wave - NWC) & 3;

@@ -14,7 +14,17 @@ int gemm_halo_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, hipSt
   if (d->kh != 3 || d->kw != 3 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->cls_h >= 0) return 0;
   if (d->sh != 1 && !(fwd && d->sh == 2)) return 0;                           // forward also with a row stride of 2 (layer1.0.conv1)
   if (d->Ho != (d->Hi - 1) / d->sh + 1 || d->Wo != d->Wi || (d->Wi % 256) != 0) return 0;    // an M tile = 256 pixels of one image row
-  if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->c_f32) return 0;
+  if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1) return 0;
+  if (d->c_f32) {
+    // float32 C (the split-bf16 parity path's convolutions): plain stores from the accumulators, alpha, an optional float32 residual
+    // on dgrad, per-tile column sums on the forward -- nothing else
+    if (d->colscale != nullptr || d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->relu_src != nullptr ||
+        d->bnb_partial[0] != nullptr || d->relu_scale != nullptr || d->accumulate || (fwd && d->residual != nullptr))
+      return 0;
+    if (bn == 192) return fwd ? launch_halo<192, false, true>(p, st) : launch_halo<192, true, true>(p, st);
+    if (bn == 128) return fwd ? launch_halo<128, false, true>(p, st) : launch_halo<128, true, true>(p, st);
+    return 0;
+  }
   if ((d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;   // the staged bf16 epilogue
   // forward: raw output (+ BatchNorm column sums) in training, or the eval-mode fold C = relu?(acc * colscale + bias [+ residual])
   // -- both are paths of the shared staged epilogue; GELU / saved pre-activations do not occur on convolutions

@@ -81,6 +81,79 @@ __device__ __forceinline__ void halo_acc16_to_32(f32x16_t (&acc)[TM][TN], const 
           for (int r = 0; r < 4; ++r) acc[i][j][4 * (2 * a + b) + r] = a4[2 * i + a][2 * j + b][r];
 }
 
+// float32 C straight from the 16 x 16 accumulator tiles (the split-bf16 parity path, csrc/split.hip: its convolutions are bf16
+// products over three times the channels with float32 results; until round 5 they ran on the generic gather because the halo
+// kernels only had the LDS-staged bf16 epilogue).  a4[i][j][r] = C(row 16 i + 4 (lane >> 4) + r, column 16 j + (lane & 15)) of the
+// wave's 64 x (32 TN) block: plain stores (16 lanes = 64 contiguous bytes of one row), alpha, an optional float32 residual (dgrad),
+// and the per-tile BatchNorm column sums of the forward (wave partials through LDS, summed over the four wave rows in a fixed
+// order).  Every wave of the workgroup calls it (loader waves with active = false: they only join the barrier).
+template <int BN, int TM, int TN, int NTH, bool CSTATS, class P>
+__device__ __forceinline__ void halo_epilogue_f32(const f32x4h_t (&a4)[2 * TM][2 * TN], const P& p, int m0, int n0, int wm, int wn,
+                                                  int tile_m, int lane, char* smem, bool active) {
+  float* const Cf = reinterpret_cast<float*>(p.C);
+  const float* const Rf = reinterpret_cast<const float*>(p.residual);
+  const int lr = lane & 15, lg = lane >> 4;
+  float s1[2 * TN], s2[2 * TN];
+#pragma unroll
+  for (int j = 0; j < 2 * TN; ++j) s1[j] = s2[j] = 0.f;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+      const int n = n0 + wn * TN * 32 + 16 * j + lr;
+      const bool nok = n < p.N;
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + 16 * i + 4 * lg + r;
+          const float a = a4[i][j][r];       // rows >= M and columns >= N hold exact zeros (zero-filled operands)
+          if constexpr (CSTATS) {
+            s1[j] += a;
+            s2[j] = fmaf(a, a, s2[j]);
+          }
+          if (nok && m < p.M) {
+            const long long o = (long long)m * p.ldc + n;
+            float v = a * p.alpha;
+            if (Rf != nullptr) v += Rf[o];
+            Cf[o] = v;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (CSTATS) {
+    if (p.colstats != nullptr) {      // workgroup-uniform
+      float* red = reinterpret_cast<float*>(smem);     // [4 wave rows][BN][2]; the operand stages are dead
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) {
+        float a = s1[j], q = s2[j];
+        a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+        a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+        if (lane < 16 && active) {
+          const int c = wn * TN * 32 + 16 * j + lane;
+          red[(wm * BN + c) * 2 + 0] = a;
+          red[(wm * BN + c) * 2 + 1] = q;
+        }
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < BN; c += NTH) {
+        const int n = n0 + c;
+        if (n < p.N) {
+          float a = 0.f, q = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            a += red[(w * BN + c) * 2];
+            q += red[(w * BN + c) * 2 + 1];
+          }
+          float* dst = p.colstats + (long long)tile_m * 2 * p.N;
+          dst[n] = a;
+          dst[p.N + n] = q;
+        }
+      }
+    }
+  }
+}
+
 // DGRAD = false: A rows = output pixels, source = x [B,H,W,Ci];  true: A rows = input pixels, source = dy [B,H,W,Co]
 template <int BN, bool DGRAD, class P>
 __device__ __forceinline__ void gemm_halo_body_oneloop(const P& p, const int block_x) {
@@ -667,7 +740,7 @@ int launch_halo_fs2(const KParams& p, hipStream_t st) {
 // (profiles/r05_experiments.md).  The epilogue is inlined once per role (the loader copy with a dead accumulator set).
 // ---------------------------------------------------------------------------------------------
 // (DGRAD / forward and the row stride as in gemm_halo_body_oneloop above)
-template <int BN, bool DGRAD, class P>
+template <int BN, bool DGRAD, bool F32, class P>
 __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
   using H = HaloGeo<BN>;
   constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
@@ -711,9 +784,13 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
     }
     __builtin_amdgcn_s_barrier();
     HTRVT_STAMP(3);
-    f32x16_t acc[TM][TN];
-    halo_acc16_to_32<TM, TN>(acc, a4);
-    epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+    if constexpr (F32) {
+      halo_epilogue_f32<BN, TM, TN, NW_TOTAL * 64, !DGRAD>(a4, p, m0, n0, wm, wn, tile_m, lane, smem, true);
+    } else {
+      f32x16_t acc[TM][TN];
+      halo_acc16_to_32<TM, TN>(acc, a4);
+      epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+    }
     HTRVT_STAMP(6);
 #ifdef HTRVT_EXP_STAMP      // experiment builds: when have this wave's stores drained, and on which CU did the tile run
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -791,6 +868,14 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    if constexpr (F32) {
+      f32x4h_t z4[2 * TM][2 * TN];
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) z4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+      halo_epilogue_f32<BN, TM, TN, NW_TOTAL * 64, !DGRAD>(z4, p, m0, n0, wm, wn, tile_m, lane, smem, false);
+    } else {
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -799,10 +884,11 @@ __device__ __forceinline__ void gemm_halo_body(const P& p, const int block_x) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     epilogue_staged<TN, BN, BM, NW_TOTAL, DGRAD, !DGRAD, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, false);
+    }
   }
 }
 
-template <int BN, bool DGRAD>
+template <int BN, bool DGRAD, bool F32 = false>
 __global__ __launch_bounds__(768) void gemm_halo_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;
   (void)p;
@@ -810,15 +896,15 @@ __global__ __launch_bounds__(768) void gemm_halo_kernel(const KParams p) {
 #ifdef HTRVT_HALO_ONELOOP      // A/B builds: consumer and loader waves in ONE copy of the loop (rounds 3-4)
   gemm_halo_body_oneloop<BN, DGRAD>(*kp, (int)blockIdx.x);
 #else
-  gemm_halo_body<BN, DGRAD>(*kp, (int)blockIdx.x);
+  gemm_halo_body<BN, DGRAD, F32>(*kp, (int)blockIdx.x);
 #endif
 }
 
-template <int BN, bool DGRAD>
+template <int BN, bool DGRAD, bool F32 = false>
 int launch_halo(const KParams& p, hipStream_t st) {
   using H = HaloGeo<BN>;
   static bool attr_done = false;
-  auto kern = gemm_halo_kernel<BN, DGRAD>;
+  auto kern = gemm_halo_kernel<BN, DGRAD, F32>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS_BYTES);
     if (e != hipSuccess) {
@@ -828,7 +914,8 @@ int launch_halo(const KParams& p, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), H::LDS_BYTES, st, p);
-  set_last_kernel("gemm_halo_kernel<%d, %s>", BN, DGRAD ? "true" : "false");
+  if (F32) set_last_kernel("gemm_halo_kernel<%d, %s, f32>", BN, DGRAD ? "true" : "false");
+  else set_last_kernel("gemm_halo_kernel<%d, %s>", BN, DGRAD ? "true" : "false");
   const int rc = check_launch("gemm_halo_kernel");
   return rc ? rc : 1;
 }

@@ -319,6 +319,49 @@ def test_halo_conv_forward_dgrad_exact(cfg):
         assert "gemm_halo_kernel" in outs[12] or "gemm_halo_kernel" in _last_kernel(), (outs, _last_kernel())
 
 
+@pytest.mark.parametrize("cfg", [(2, 4, 256, 192, 192), (3, 2, 512, 384, 384), (1, 1, 256, 64, 128), (2, 3, 256, 96, 256)])
+def test_halo_conv_float32_output_exact(cfg):
+    """the halo kernels with float32 C (round 5: the convolutions of the split-bf16 parity path): forward + per-tile column sums,
+    dgrad with and without a float32 residual, against torch's float64 convolution on integer data -- exact, no rounding of the
+    result -- and the generic gather (tile 5) beside them"""
+    ops = T._ops()
+    Bn, Hh, Ww, Ci, Co = cfg
+    x = T._ints((Bn, Ci, Hh, Ww), -2, 3, seed=150).requires_grad_(True)
+    w = T._ints((Co, Ci, 3, 3), -2, 3, seed=151)
+    y = F.conv2d(x, w, None, stride=1, padding=1)
+    dy = T._ints(tuple(y.shape), -2, 3, seed=152)
+    y.backward(dy)
+    geom = ops.ConvGeom(Bn, Hh, Ww, Ci, Co, 3, (1, 1), 1)
+    M = Bn * Hh * Ww
+    cpi, cpo = ops.cpad(Ci, BF), ops.cpad(Co, BF)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wf = T._pack_fwd(w, cpi).to(BF).cuda()
+    y_nhwc = y.detach().permute(0, 2, 3, 1)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    wd = T._pack_dgrad(w, cpo).to(BF).cuda()
+    res = T._ints((Bn, Hh, Ww, Ci), -50, 51, seed=153)
+    dx_ref = x.grad.permute(0, 2, 3, 1)
+    for tile in (12, 5):
+        yd = torch.full((Bn, Hh, Ww, Co), 9.0, dtype=torch.float32, device="cuda")
+        nmt = ops.gemm_num_mtiles(M, Co, BF, gather=ops.GATHER_CONV_FWD)
+        cs = torch.full((nmt, 2, Co), float("nan"), dtype=torch.float32, device="cuda")
+        ops.gemm(xd, wf, yd, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+                 Cpad=cpi, colstats=cs, c_f32=True, tile=tile)
+        if tile == 12 and Co >= 96:
+            assert "gemm_halo_kernel" in _last_kernel() and "f32" in _last_kernel(), _last_kernel()
+        assert torch.equal(yd.double().cpu(), y_nhwc), (tile, _last_kernel(), float((yd.double().cpu() - y_nhwc).abs().max()))
+        yy = y_nhwc.reshape(-1, Co)
+        want = torch.stack([torch.stack([yy[r0:r0 + 256].sum(0), (yy[r0:r0 + 256] ** 2).sum(0)]) for r0 in range(0, M, 256)])
+        assert torch.equal(cs.double().cpu(), want), (tile, _last_kernel())
+        for with_res in (False, True):
+            dxd = torch.full((Bn, Hh, Ww, Ci), 9.0, dtype=torch.float32, device="cuda")
+            ops.gemm(dyd, wd, dxd, dtype=BF, M=M, N=Ci, K=9 * cpo, lda=Co, ldb=9 * cpo, ldc=Ci, gather=ops.GATHER_CONV_DGRAD, geom=geom,
+                     Cpad=cpo, c_f32=True, residual=res.float().cuda() if with_res else None, tile=tile)
+            if tile == 12 and Ci >= 96:
+                assert "gemm_halo_kernel" in _last_kernel() and "f32" in _last_kernel(), _last_kernel()
+            assert torch.equal(dxd.double().cpu(), dx_ref + (res if with_res else 0.0)), (tile, with_res, _last_kernel())
+
+
 @pytest.mark.parametrize("cfg", [(2, 2, 256, 192, 192), (1, 3, 512, 128, 384)])
 def test_halo_conv_forward_eval_fold_exact(cfg):
     """eval-mode BatchNorm (+ residual + ReLU) folded into a halo-staged 3x3 convolution: relu(conv * scale + shift + res),

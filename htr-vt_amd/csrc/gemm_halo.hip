@@ -43,7 +43,13 @@ int gemm_halo_fs2_try_launch(const HtrvtGemmDesc* d, const KParams& p, int bn, h
   if (d->tile != 0 && d->tile != 4 && d->tile != 12) return 0;      // 5: the generic gather (A/B)
   if (d->kh != 3 || d->kw != 3 || d->sw != 2 || (d->sh != 1 && d->sh != 2) || d->ph != 1 || d->pw != 1 || d->cls_h >= 0) return 0;
   if ((d->Wi & 1) || d->Wo != d->Wi / 2 || d->Ho != (d->Hi - 1) / d->sh + 1 || (d->Wo % 256) != 0) return 0;   // an M tile = 256 pixels of one output row
-  if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->c_f32 || d->M != d->nB * d->Ho * d->Wo) return 0;
+  if (d->K != 9 * d->Cpad || d->batch > 1 || d->split_k > 1 || d->M != d->nB * d->Ho * d->Wo) return 0;
+  if (d->c_f32) {      // float32 C + per-tile column sums (the split-bf16 parity path), as in gemm_halo_try_launch
+    if (d->colscale != nullptr || d->bias != nullptr || d->act != 0 || d->preact != nullptr || d->residual != nullptr || d->accumulate) return 0;
+    if (bn == 192) return launch_halo_fs2<192, true>(p, st);
+    if (bn == 128) return launch_halo_fs2<128, true>(p, st);
+    return 0;
+  }
   if ((d->ldc & 7) || (d->N & 7) || (reinterpret_cast<unsigned long long>(d->C) & 15)) return 0;   // the staged bf16 epilogue
   if (d->preact != nullptr || (d->act != 0 && d->act != 3)) return 0;
   if (d->residual != nullptr && d->colscale == nullptr) return 0;    // a residual only as part of the eval fold

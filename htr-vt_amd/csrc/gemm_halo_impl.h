@@ -582,7 +582,7 @@ struct HaloFs2Geo {
   static_assert(LDS_BYTES >= BN * Stg<256>::CST, "the staged epilogue's column-major image");
 };
 
-template <int BN, class P>
+template <int BN, bool F32, class P>
 __device__ __forceinline__ void gemm_halo_fs2_body(const P& p, const int block_x) {
   using H = HaloFs2Geo<BN>;
   constexpr int BM = 256, NWC = 8, NW_TOTAL = 12, TM = 2, TN = BN / 64;
@@ -619,9 +619,13 @@ __device__ __forceinline__ void gemm_halo_fs2_body(const P& p, const int block_x
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_s_barrier();
-    f32x16_t acc[TM][TN];
-    halo_acc16_to_32<TM, TN>(acc, a4);
-    epilogue_staged<TN, BN, BM, NW_TOTAL, false, true, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+    if constexpr (F32) {
+      halo_epilogue_f32<BN, TM, TN, NW_TOTAL * 64, true>(a4, p, m0, n0, wm, wn, tile_m, lane, smem, true);
+    } else {
+      f32x16_t acc[TM][TN];
+      halo_acc16_to_32<TM, TN>(acc, a4);
+      epilogue_staged<TN, BN, BM, NW_TOTAL, false, true, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, true);
+    }
   } else {
     // ================================ loader waves ================================
     const int lw = (wave - NWC) & 3;
@@ -694,6 +698,14 @@ __device__ __forceinline__ void gemm_halo_fs2_body(const P& p, const int block_x
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill pieces issued past the last k-tile
     __builtin_amdgcn_s_barrier();
+    if constexpr (F32) {
+      f32x4h_t z4[2 * TM][2 * TN];
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) z4[i][j] = f32x4h_t{0.f, 0.f, 0.f, 0.f};
+      halo_epilogue_f32<BN, TM, TN, NW_TOTAL * 64, true>(z4, p, m0, n0, wm, wn, tile_m, lane, smem, false);
+    } else {
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -702,22 +714,23 @@ __device__ __forceinline__ void gemm_halo_fs2_body(const P& p, const int block_x
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     epilogue_staged<TN, BN, BM, NW_TOTAL, false, true, P, 16>(acc, p, 0ll, m0, n0, wm, wn, tile_m, lane, wave, smem, false);
+    }
   }
 }
 
-template <int BN>
+template <int BN, bool F32 = false>
 __global__ __launch_bounds__(768) void gemm_halo_fs2_kernel(const KParams p) {
   typedef const __attribute__((address_space(4))) KParams KP;
   (void)p;
   KP* kp = (KP*)__builtin_amdgcn_kernarg_segment_ptr();
-  gemm_halo_fs2_body<BN>(*kp, (int)blockIdx.x);
+  gemm_halo_fs2_body<BN, F32>(*kp, (int)blockIdx.x);
 }
 
-template <int BN>
+template <int BN, bool F32 = false>
 int launch_halo_fs2(const KParams& p, hipStream_t st) {
   constexpr int LDS = HaloFs2Geo<BN>::LDS_BYTES;
   static bool attr_done = false;
-  auto kern = gemm_halo_fs2_kernel<BN>;
+  auto kern = gemm_halo_fs2_kernel<BN, F32>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
@@ -727,7 +740,8 @@ int launch_halo_fs2(const KParams& p, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(768), LDS, st, p);
-  set_last_kernel("gemm_halo_fs2_kernel<%d>", BN);
+  if (F32) set_last_kernel("gemm_halo_fs2_kernel<%d, f32>", BN);
+  else set_last_kernel("gemm_halo_fs2_kernel<%d>", BN);
   const int rc = check_launch("gemm_halo_fs2_kernel");
   return rc ? rc : 1;
 }

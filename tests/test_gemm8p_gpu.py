@@ -242,6 +242,16 @@ def test_halo_conv_col_stride_forward_exact(cfg):
         assert torch.equal(yd.double().cpu(), y_nhwc.to(BF).double()), (tile, _last_kernel(), float((yd.double().cpu() - y_nhwc).abs().max()))
         assert torch.allclose(cs[:, 0].sum(0).double().cpu(), y_nhwc.reshape(-1, Co).sum(0), rtol=1e-6, atol=1e-3)
         assert torch.allclose(cs[:, 1].sum(0).double().cpu(), (y_nhwc.reshape(-1, Co) ** 2).sum(0), rtol=1e-6, atol=1e-3)
+    # float32 C (the split-bf16 path's form of this convolution): exact sums, per-tile column sums
+    yf = torch.full((Bn, geom.Ho, geom.Wo, Co), 9.0, dtype=torch.float32, device="cuda")
+    nmt = ops.gemm_num_mtiles(M, Co, BF, gather=ops.GATHER_CONV_FWD)
+    csf = torch.full((nmt, 2, Co), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm(xd, wf, yf, dtype=BF, M=M, N=Co, K=9 * cpi, lda=Ci, ldb=9 * cpi, ldc=Co, gather=ops.GATHER_CONV_FWD, geom=geom,
+             Cpad=cpi, colstats=csf, c_f32=True, tile=12)
+    assert "gemm_halo_fs2_kernel" in _last_kernel() and "f32" in _last_kernel(), _last_kernel()
+    assert torch.equal(yf.double().cpu(), y_nhwc)
+    yy = y_nhwc.reshape(-1, Co)
+    assert torch.equal(csf.double().cpu(), torch.stack([torch.stack([yy[r0:r0 + 256].sum(0), (yy[r0:r0 + 256] ** 2).sum(0)]) for r0 in range(0, M, 256)]))
     g = torch.Generator().manual_seed(92)
     scale = torch.tensor([0.25, 0.5, 1.0, -0.5])[torch.randint(0, 4, (Co,), generator=g)].double()
     shift = torch.randint(-8, 9, (Co,), generator=g).double()
